@@ -1,0 +1,141 @@
+/*
+ * slam_engine.h - C ABI of libslam_engine.so, the gfx950 (MI355X) engine behind slamkit's
+ * cli/train.py hot path.
+ *
+ * The reference has no FFI on this path: the boundary is the Python plugin surface
+ *   tlm_factory(cfg.model) -> TokenLM            /root/reference slamkit/model/token_lm.py:30-43
+ *   UnitLM.forward(input_ids, attention_mask, position_ids, labels, num_items_in_batch)
+ *                                                 slamkit/model/unit_lm.py:135-182
+ *   compute_loss(logits, labels, num_items_in_batch)   slamkit/model/unit_lm.py:13-29
+ *   UnitLM.log_likelihood                          slamkit/model/unit_lm.py:184-194
+ *   SLAMTrainer.training_step + HF Trainer step    slamkit/trainer/slam_trainer.py:59-71
+ * Each entry point below names the reference call it replaces. All device pointers are BORROWED
+ * (PyTorch-ROCm tensor.data_ptr()); the engine never frees them and never synchronises the host:
+ * every call only enqueues work on the hipStream_t it is given. Return value 0 = ok, negative =
+ * SLAM_E*, positive = hipError_t; slam_last_error() gives text. No exceptions cross the ABI.
+ * One engine per process/GPU; calls on one engine must be serialised by the caller.
+ */
+#ifndef SLAM_ENGINE_H
+#define SLAM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK 0
+#define SLAM_EINVAL (-1)      /* bad argument / unsupported shape */
+#define SLAM_ESTATE (-2)      /* call order (e.g. backward without forward, unbound buffers) */
+#define SLAM_ENOMEM (-3)      /* bound workspace too small */
+
+typedef struct SlamEngine SlamEngine;
+typedef void* slam_stream_t; /* hipStream_t */
+
+/* Qwen2-shaped decoder description (UnitLMConfig.base_config, unit_lm.py:32-79; Slam-358M values
+ * from config/model/slam.yaml + Qwen2.5-0.5B). */
+typedef struct SlamModelDesc {
+  int32_t n_layers;      /* 24  */
+  int32_t hidden;        /* 896 */
+  int32_t n_heads;       /* 14  */
+  int32_t n_kv_heads;    /* 2   */
+  int32_t head_dim;      /* 64 (only 64 supported) */
+  int32_t intermediate;  /* 4864 */
+  int32_t vocab;         /* 502 (<= 512 supported; rows padded to 512 internally) */
+  int32_t pad_token_id;  /* 0: nn.Embedding(padding_idx) gather-gradient suppression; -1 = none */
+  float rms_eps;         /* 1e-6 */
+  float rope_theta;      /* 10000 */
+} SlamModelDesc;
+
+typedef struct SlamTensorInfo {
+  char name[64];      /* "embed", "layers.3.wqkv", "layers.3.bqkv", "layers.3.wo", "layers.3.ln1",
+                         "layers.3.ln2", "layers.3.wgu", "layers.3.wd", "norm" */
+  int64_t offset;     /* element offset in the flat parameter / gradient buffers */
+  int64_t rows, cols; /* row-major [rows][cols] (cols = 1 for vectors) */
+} SlamTensorInfo;
+
+/* Called from slam_backward (host side, after the producing kernels were enqueued) when the
+ * gradient range [offset, offset+count) of the flat fp32 gradient buffer is final. Used by the
+ * data-parallel reducer to launch RCCL all-reduces overlapped with the rest of backward
+ * (replaces torch DDP's reducer hooks). */
+typedef void (*slam_bucket_cb)(void* user, int64_t offset, int64_t count);
+
+/* ---- lifetime -------------------------------------------------------------------------------*/
+int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out); /* UnitLM.__init__ :91-112 */
+void slam_engine_destroy(SlamEngine* h);
+const char* slam_last_error(SlamEngine* h);
+const char* slam_version(void);
+
+/* ---- parameter layout -----------------------------------------------------------------------*/
+int64_t slam_param_count(SlamEngine* h);   /* elements in the flat buffers (padded vocab rows incl.) */
+int32_t slam_tensor_count(SlamEngine* h);
+int slam_tensor_info(SlamEngine* h, int32_t index, SlamTensorInfo* out);
+/* params: bf16 [slam_param_count], grads: fp32 [slam_param_count] (model.parameters() / .grad) */
+int slam_bind_params(SlamEngine* h, void* params_bf16, float* grads_f32);
+
+/* ---- workspace ------------------------------------------------------------------------------*/
+size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens);
+int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_tokens);
+
+/* ---- forward / loss: UnitLM.forward + compute_loss (unit_lm.py:13-29,135-182) ----------------
+ * ids/labels/position_ids: int64 [B*T] device (labels, position_ids nullable).
+ * seg_start/seg_end: int32 [B*T] device, nullable -> dense rows of length T. For packed batches
+ *   ([1, sum T] from DataCollatorWithFlattening) they give each token's sequence bounds.
+ * num_items > 0 -> loss = sum / num_items (reduction "sum"), else mean over valid targets.
+ * loss_out: fp32 [1] device (nullable when labels is NULL); logits_out: bf16 [B*T*vocab] device,
+ * nullable. */
+int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const int64_t* position_ids,
+                 const int32_t* seg_start, const int32_t* seg_end, int32_t B, int32_t T, double num_items,
+                 float* loss_out, void* logits_out, slam_stream_t stream);
+
+/* loss.backward(): accumulates d(loss*grad_scale)/dparam into the bound fp32 gradient buffer.
+ * bucket_layers = decoder layers per gradient bucket for the callback (<=0: one bucket). */
+int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_bucket_cb cb, void* user,
+                  slam_stream_t stream);
+
+/* Per-sequence log-likelihood sums of the last forward (UnitLM.log_likelihood :184-194 /
+ * calc_nll, slamkit/utils/calculation_utils.py:5-29): ll_out, cnt_out fp32 [B] device. */
+int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, float* ll_out, float* cnt_out,
+                    slam_stream_t stream);
+
+/* ---- optimizer step: HF Trainer clip_grad_norm_ + torch AdamW --------------
+ * norm_out: fp32 [2] device = {global grad norm, clip coefficient}. */
+int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream);
+int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp_avg_sq, const float* norm_out,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
+                    int32_t zero_grad, slam_stream_t stream);
+int slam_zero_grads(SlamEngine* h, slam_stream_t stream);
+int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t stream); /* fp32 -> bound bf16 */
+
+/* ---- tuning knobs ---------------------------------------------------------------------------*/
+int slam_set_option(SlamEngine* h, const char* key, int64_t value); /* "gemm_glds" = 0|1 */
+
+/* ---- single-op entry points (parity tests call each kernel through the ABI) -------------------*/
+int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
+                    int use_glds, slam_stream_t s);
+int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s);
+size_t slam_op_gemm_tn_workspace(int M, int N, int K);
+int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,
+                    slam_stream_t s);
+int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s);
+size_t slam_op_rmsnorm_bwd_workspace(int M, int H);
+int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                        float* dw, float* ws, int M, int H, slam_stream_t s);
+int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, const int64_t* position_ids, float theta,
+                 int backward, float* cos_sin_ws /* 2*M*32 floats */, slam_stream_t s);
+int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s);
+int slam_op_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, slam_stream_t s);
+int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
+                     slam_stream_t s);
+size_t slam_op_attn_bwd_workspace(int M, int nH);
+int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
+                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, slam_stream_t s);
+int slam_op_cross_entropy(const void* logits /* bf16 [B*T][512] */, const int64_t* labels, double num_items,
+                          void* dlogits, float* row_loss, float* scratch2 /* {denom, loss} */, int B, int T, int V,
+                          slam_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_ENGINE_H */

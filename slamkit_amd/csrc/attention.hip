@@ -1,0 +1,486 @@
+// Causal grouped-query flash attention (head_dim 64) for gfx950, forward + backward, over a packed
+// token axis: row m of qkv[M][(nH+2nKV)*64] attends rows seg_start[m] <= j <= m. Dense [B,T]
+// batches are the special case seg_start = (m/T)*T; right padding needs no key mask (a real
+// query never sees a later pad key under the causal mask); packed batches pass the segment
+// starts derived from position_ids == 0 (flattening collator, hf_dataset.py:61-62).
+//
+// Replaces Qwen2Attention's softmax_fp32(QKᵀ/8 + mask)·V (site-packages
+// transformers/models/qwen2/modeling_qwen2.py:138-172) and its autograd; SURVEY.md §8a T5.
+//
+// All three kernels keep the softmax tile in registers: scores are produced *transposed*
+// (MFMA a-operand = keys, b-operand = queries, or vice versa in dKV) so that the contraction
+// index of the following MFMA already sits in the (lane>>4, reg) position of the C fragment and
+// the bf16 P / dS fragment is fed straight back as an MFMA operand - no LDS round trip.
+// The matching operand is read from a transposed LDS image ([d][row], 136-byte pitch).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int XT_PITCH = 136;              // bytes per d-row of a transposed 64x64 tile
+constexpr int XT_BYTES = 64 * XT_PITCH;    // 8704
+constexpr int DT_BYTES = 64 * 128;         // direct 64x64 tile
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnArgs {
+  const bf16_t* qkv;   // [M][ldq]
+  bf16_t* o;           // [M][nH*64]            (fwd out / bwd in)
+  const bf16_t* d_o;   // [M][nH*64]
+  bf16_t* dqkv;        // [M][ldq]
+  float* lse2;         // [nH][M]  log2-domain logsumexp of scaled scores
+  float* dsum;         // [nH][M]  rowsum(dO*O)
+  float* dkv_part;     // [2][nH][M][64] fp32 per-q-head dK / dV partials
+  const int* seg_start;  // [M]
+  const int* seg_end;    // [M]
+  int M, nH, nKV, ldq;
+  float scale;         // head_dim^-0.5
+};
+
+// thread -> (row pair p, chunk dc) mapping for 64x64 tiles: rows 2p, 2p+1, 16-byte chunk dc
+SLAM_DEVICE void tile_load(const bf16_t* base, int ld, int row0, int M, int tid, uint4& r0, uint4& r1) {
+  int p = tid >> 3, dc = tid & 7;
+  int g0 = row0 + 2 * p;
+  r0 = make_uint4(0, 0, 0, 0);
+  r1 = r0;
+  if (g0 < M) r0 = *reinterpret_cast<const uint4*>(base + (size_t)g0 * ld + dc * 8);
+  if (g0 + 1 < M) r1 = *reinterpret_cast<const uint4*>(base + (size_t)(g0 + 1) * ld + dc * 8);
+}
+SLAM_DEVICE void tile_store_direct(char* tile, int tid, const uint4& r0, const uint4& r1) {
+  int p = tid >> 3, dc = tid & 7;
+  *reinterpret_cast<uint4*>(tile + lds_tile_off(2 * p, dc)) = r0;
+  *reinterpret_cast<uint4*>(tile + lds_tile_off(2 * p + 1, dc)) = r1;
+}
+SLAM_DEVICE void tile_store_transposed(char* xt, int tid, const uint4& r0, const uint4& r1) {
+  int p = tid >> 3, dc = tid & 7;
+  const uint32_t a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t x = a[i >> 1], y = b[i >> 1];
+    uint32_t w = (i & 1) ? ((x >> 16) | (y & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
+    *reinterpret_cast<uint32_t*>(xt + (dc * 8 + i) * XT_PITCH + p * 4) = w;
+  }
+}
+// a-operand fragment from a direct tile: row = f*16 + l15, d-block g + 4*ds
+SLAM_DEVICE uint4 frag_direct(const char* tile, int f, int l15, int g, int ds) {
+  return *reinterpret_cast<const uint4*>(tile + lds_tile_off(f * 16 + l15, g + 4 * ds));
+}
+// a-operand fragment from a transposed tile for contraction step t: d = fd*16 + l15,
+// rows {32t + 4g + r} U {32t + 16 + 4g + r}, r = 0..3 (the order the P/dS b-operand is packed in)
+SLAM_DEVICE uint4 frag_transposed(const char* xt, int fd, int l15, int g, int t) {
+  const char* base = xt + (fd * 16 + l15) * XT_PITCH + (32 * t + 4 * g) * 2;
+  uint2 lo = *reinterpret_cast<const uint2*>(base);
+  uint2 hi = *reinterpret_cast<const uint2*>(base + 32);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
+  return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                    pack_bf16x2(b[2], b[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward. grid (ceil(M/128), nH); wave w owns query rows q0+32w .. +31 (two 16-row fragments).
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[DT_BYTES + XT_BYTES];
+  char* Ks = smem;
+  char* Vt = smem + DT_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
+  const int q0 = blockIdx.x * 128;
+  const int qw0 = q0 + wave * 32;
+  const int M = p.M, ld = p.ldq;
+  const bf16_t* Qb = p.qkv + h * 64;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
+  const float c2 = p.scale * 1.44269504088896340736f;
+
+  int qrow[2], segs[2];
+  uint4 qf[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int q = qw0 + j * 16 + l15;
+    qrow[j] = q;
+    int qc = q < M ? q : M - 1;
+    segs[j] = p.seg_start[qc];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds)
+      qf[j][ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
+  }
+  f32x4_t ot[4][2];
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
+
+  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
+  const int kt_end = (min(q0 + 127, M - 1)) / 64;
+  uint4 kr0, kr1, vr0, vr1;
+  tile_load(Kb, ld, kt_begin * 64, M, tid, kr0, kr1);
+  tile_load(Vb, ld, kt_begin * 64, M, tid, vr0, vr1);
+  for (int kt = kt_begin; kt <= kt_end; ++kt) {
+    tile_store_direct(Ks, tid, kr0, kr1);
+    tile_store_transposed(Vt, tid, vr0, vr1);
+    __syncthreads();
+    if (kt < kt_end) {
+      tile_load(Kb, ld, (kt + 1) * 64, M, tid, kr0, kr1);
+      tile_load(Vb, ld, (kt + 1) * 64, M, tid, vr0, vr1);
+    }
+    const int key0 = kt * 64;
+    if (key0 <= qw0 + 31) {  // wave-uniform: tile not entirely above this wave's diagonal
+      f32x4_t st[4][2];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          uint4 kf = frag_direct(Ks, f, l15, g, ds);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
+        }
+      uint4 pb[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float mx = NEG_BIG;
+        bool ok[4][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = key0 + f * 16 + g * 4 + r;
+            ok[f][r] = (key <= qrow[j]) && (key >= segs[j]);
+            float s = ok[f][r] ? st[f][j][r] * c2 : NEG_BIG;
+            st[f][j][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun[j], mx);
+        const float alpha = exp2f(mrun[j] - mnew);
+        mrun[j] = mnew;
+        float ps = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float e = ok[f][r] ? exp2f(st[f][j][r] - mnew) : 0.f;
+            st[f][j][r] = e;
+            ps += e;
+          }
+        lsum[j] = lsum[j] * alpha + ps;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+        pb[0][j] = pack_pair(st[0][j], st[1][j]);
+        pb[1][j] = pack_pair(st[2][j], st[3][j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          uint4 vf = frag_transposed(Vt, fd, l15, g, t);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf, pb[t][j], ot[fd][j]);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float l = lsum[j];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int q = qrow[j];
+    if (q < M) {
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        uint2 o;
+        o.x = pack_bf16x2(ot[fd][j][0] * inv, ot[fd][j][1] * inv);
+        o.y = pack_bf16x2(ot[fd][j][2] * inv, ot[fd][j][3] * inv);
+        *reinterpret_cast<uint2*>(p.o + (size_t)q * (p.nH * 64) + h * 64 + fd * 16 + g * 4) = o;
+      }
+      if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = mrun[j] + log2f(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dsum[h][m] = sum_d dO[m][h*64+d] * O[m][h*64+d]
+__global__ __launch_bounds__(256) void attn_dsum_kernel(AttnArgs p) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.M * p.nH) return;
+  int m = (int)(idx / p.nH), h = (int)(idx % p.nH);
+  const uint4* a = reinterpret_cast<const uint4*>(p.d_o + (size_t)m * p.nH * 64 + h * 64);
+  const uint4* b = reinterpret_cast<const uint4*>(p.o + (size_t)m * p.nH * 64 + h * 64);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float x[8], y[8];
+    unpack_bf16x8(a[c], x);
+    unpack_bf16x8(b[c], y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j] * y[j];
+  }
+  p.dsum[(size_t)h * p.M + m] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * DT_BYTES + XT_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + DT_BYTES;
+  char* Kt = smem + 2 * DT_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
+  const int q0 = blockIdx.x * 64;
+  const int qw0 = q0 + wave * 16;
+  const int M = p.M, ld = p.ldq;
+  const bf16_t* Qb = p.qkv + h * 64;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
+  const float c2 = p.scale * 1.44269504088896340736f;
+
+  const int q = qw0 + l15;
+  const int qc = q < M ? q : M - 1;
+  const int seg = p.seg_start[qc];
+  const float lse = p.lse2[(size_t)h * M + qc];
+  const float dsm = p.dsum[(size_t)h * M + qc];
+  uint4 qf[2], dof[2];
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds) {
+    qf[ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
+    dof[ds] = *reinterpret_cast<const uint4*>(p.d_o + (size_t)qc * p.nH * 64 + h * 64 + g * 8 + 32 * ds);
+  }
+  f32x4_t dq[4];
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
+  const int kt_end = (min(q0 + 63, M - 1)) / 64;
+  uint4 kr0, kr1, vr0, vr1;
+  tile_load(Kb, ld, kt_begin * 64, M, tid, kr0, kr1);
+  tile_load(Vb, ld, kt_begin * 64, M, tid, vr0, vr1);
+  for (int kt = kt_begin; kt <= kt_end; ++kt) {
+    tile_store_direct(Ks, tid, kr0, kr1);
+    tile_store_transposed(Kt, tid, kr0, kr1);
+    tile_store_direct(Vs, tid, vr0, vr1);
+    __syncthreads();
+    if (kt < kt_end) {
+      tile_load(Kb, ld, (kt + 1) * 64, M, tid, kr0, kr1);
+      tile_load(Vb, ld, (kt + 1) * 64, M, tid, vr0, vr1);
+    }
+    const int key0 = kt * 64;
+    if (key0 <= qw0 + 15) {
+      f32x4_t st[4], dp[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { st[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[f] = st[f]; }
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          st[f] = mfma16(frag_direct(Ks, f, l15, g, ds), qf[ds], st[f]);
+          dp[f] = mfma16(frag_direct(Vs, f, l15, g, ds), dof[ds], dp[f]);
+        }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = key0 + f * 16 + g * 4 + r;
+          bool ok = (key <= q) && (key >= seg) && (q < M);
+          float pe = ok ? exp2f(st[f][r] * c2 - lse) : 0.f;
+          st[f][r] = pe * (dp[f][r] - dsm);
+        }
+      uint4 dsb[2] = {pack_pair(st[0], st[1]), pack_pair(st[2], st[3])};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) dq[fd] = mfma16(frag_transposed(Kt, fd, l15, g, t), dsb[t], dq[fd]);
+    }
+    __syncthreads();
+  }
+  if (q < M) {
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+      uint2 o;
+      o.x = pack_bf16x2(dq[fd][0] * p.scale, dq[fd][1] * p.scale);
+      o.y = pack_bf16x2(dq[fd][2] * p.scale, dq[fd][3] * p.scale);
+      *reinterpret_cast<uint2*>(p.dqkv + (size_t)q * ld + h * 64 + fd * 16 + g * 4) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dK / dV per query head. grid (ceil(M/64), nH); wave w owns keys k0+16w .. +15; fp32 partials
+// dkv_part[0|1][h][m][64] are summed over the heads of a KV group by attn_dkv_reduce_kernel.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * DT_BYTES + 2 * XT_BYTES + 3 * 256];
+  char* Qs = smem;
+  char* dOs = smem + DT_BYTES;
+  char* Qt = smem + 2 * DT_BYTES;
+  char* dOt = Qt + XT_BYTES;
+  float* lse_s = reinterpret_cast<float*>(dOt + XT_BYTES);
+  float* dsm_s = lse_s + 64;
+  int* seg_s = reinterpret_cast<int*>(dsm_s + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
+  const int k0 = blockIdx.x * 64;
+  const int M = p.M, ld = p.ldq, ldo = p.nH * 64;
+  const bf16_t* Qb = p.qkv + h * 64;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
+  const bf16_t* dOb = p.d_o + h * 64;
+  const float c2 = p.scale * 1.44269504088896340736f;
+
+  const int key = k0 + wave * 16 + l15;
+  const int kc = key < M ? key : M - 1;
+  uint4 kf[2], vf[2];
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds) {
+    kf[ds] = *reinterpret_cast<const uint4*>(Kb + (size_t)kc * ld + g * 8 + 32 * ds);
+    vf[ds] = *reinterpret_cast<const uint4*>(Vb + (size_t)kc * ld + g * 8 + 32 * ds);
+  }
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) { dk[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[fd] = dk[fd]; }
+
+  const int qt_begin = k0 / 64;
+  const int qt_end = (p.seg_end[min(k0 + 63, M - 1)] - 1) / 64;
+  uint4 qr0, qr1, gr0, gr1;
+  tile_load(Qb, ld, qt_begin * 64, M, tid, qr0, qr1);
+  tile_load(dOb, ldo, qt_begin * 64, M, tid, gr0, gr1);
+  for (int qt = qt_begin; qt <= qt_end; ++qt) {
+    const int qbase = qt * 64;
+    tile_store_direct(Qs, tid, qr0, qr1);
+    tile_store_transposed(Qt, tid, qr0, qr1);
+    tile_store_direct(dOs, tid, gr0, gr1);
+    tile_store_transposed(dOt, tid, gr0, gr1);
+    if (tid < 64) {
+      int qq = qbase + tid;
+      int qcl = qq < M ? qq : M - 1;
+      lse_s[tid] = p.lse2[(size_t)h * M + qcl];
+      dsm_s[tid] = p.dsum[(size_t)h * M + qcl];
+      seg_s[tid] = qq < M ? p.seg_start[qcl] : 0x7fffffff;  // rows past M never validate
+    }
+    __syncthreads();
+    if (qt < qt_end) {
+      tile_load(Qb, ld, (qt + 1) * 64, M, tid, qr0, qr1);
+      tile_load(dOb, ldo, (qt + 1) * 64, M, tid, gr0, gr1);
+    }
+    if (qbase + 63 >= k0 + wave * 16) {  // some query of the tile can see this wave's keys
+      f32x4_t s[4], dp[4];
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) { s[jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[jq] = s[jq]; }
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+          s[jq] = mfma16(frag_direct(Qs, jq, l15, g, ds), kf[ds], s[jq]);
+          dp[jq] = mfma16(frag_direct(dOs, jq, l15, g, ds), vf[ds], dp[jq]);
+        }
+      // lane holds (q = qbase + jq*16 + 4g + r, key)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + jq * 16 + g * 4);
+        const float4 d4 = *reinterpret_cast<const float4*>(dsm_s + jq * 16 + g * 4);
+        const int4 s4 = *reinterpret_cast<const int4*>(seg_s + jq * 16 + g * 4);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int qq = qbase + jq * 16 + g * 4 + r;
+          bool ok = (key <= qq) && (key >= sv[r]);
+          float pe = ok ? exp2f(s[jq][r] * c2 - lv[r]) : 0.f;
+          s[jq][r] = pe;
+          dp[jq][r] = pe * (dp[jq][r] - dvv[r]);
+        }
+      }
+      uint4 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+      uint4 dsb[2] = {pack_pair(dp[0], dp[1]), pack_pair(dp[2], dp[3])};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          dv[fd] = mfma16(frag_transposed(dOt, fd, l15, g, t), pb[t], dv[fd]);
+          dk[fd] = mfma16(frag_transposed(Qt, fd, l15, g, t), dsb[t], dk[fd]);
+        }
+    }
+    __syncthreads();
+  }
+  if (key < M) {
+    float* dkp = p.dkv_part + ((size_t)h * M + key) * 64;
+    float* dvp = p.dkv_part + ((size_t)(p.nH + h) * M + key) * 64;
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) {
+      *reinterpret_cast<float4*>(dkp + fd * 16 + g * 4) =
+          make_float4(dk[fd][0] * p.scale, dk[fd][1] * p.scale, dk[fd][2] * p.scale, dk[fd][3] * p.scale);
+      *reinterpret_cast<float4*>(dvp + fd * 16 + g * 4) = make_float4(dv[fd][0], dv[fd][1], dv[fd][2], dv[fd][3]);
+    }
+  }
+}
+
+// dqkv[m][K head kvh / V head kvh] = bf16( sum over the group's query heads of the partials )
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (which, m, kvh, chunk of 4)
+  const int grp = p.nH / p.nKV;
+  size_t total = (size_t)2 * p.M * p.nKV * 16;
+  if (idx >= total) return;
+  int c = idx & 15;
+  size_t r = idx >> 4;
+  int kvh = r % p.nKV; r /= p.nKV;
+  int m = r % p.M;
+  int which = (int)(r / p.M);
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int i = 0; i < grp; ++i) {
+    int h = kvh * grp + i;
+    float4 v = *reinterpret_cast<const float4*>(p.dkv_part + (((size_t)which * p.nH + h) * p.M + m) * 64 + c * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  uint2 o;
+  o.x = pack_bf16x2(s.x, s.y);
+  o.y = pack_bf16x2(s.z, s.w);
+  int col = (p.nH + (which ? p.nKV : 0) + kvh) * 64 + c * 4;
+  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col) = o;
+}
+
+}  // namespace
+
+namespace slam {
+
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, int M, int nH, int nKV,
+             int head_dim, hipStream_t st) {
+  if (head_dim != 64 || nH % nKV) return -1;
+  AttnArgs a{};
+  a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start;
+  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
+  attn_fwd_kernel<<<dim3((M + 127) / 128, nH), 256, 0, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+size_t attn_bwd_workspace_bytes(int M, int nH) { return (size_t)2 * nH * M * 64 * sizeof(float); }
+
+int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum,
+             bf16_t* dqkv, float* dkv_part, const int* seg_start, const int* seg_end, int M, int nH, int nKV,
+             int head_dim, hipStream_t st) {
+  if (head_dim != 64 || nH % nKV) return -1;
+  AttnArgs a{};
+  a.qkv = qkv; a.o = const_cast<bf16_t*>(o); a.d_o = d_o; a.dqkv = dqkv;
+  a.lse2 = const_cast<float*>(lse2); a.dsum = dsum; a.dkv_part = dkv_part;
+  a.seg_start = seg_start; a.seg_end = seg_end;
+  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
+  attn_dsum_kernel<<<(unsigned)(((size_t)M * nH + 255) / 256), 256, 0, st>>>(a);
+  attn_bwd_dq_kernel<<<dim3((M + 63) / 64, nH), 256, 0, st>>>(a);
+  attn_bwd_dkv_kernel<<<dim3((M + 63) / 64, nH), 256, 0, st>>>(a);
+  size_t total = (size_t)2 * M * nKV * 16;
+  attn_dkv_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace slam

@@ -1,0 +1,61 @@
+"""Build libslam_engine.so (gfx950) in-tree: hipcc per translation unit, then one shared link.
+
+Usage: python -m slamkit_amd.csrc.build [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_DIR = os.path.join(ROOT, "lib")
+LIB = os.path.join(LIB_DIR, "libslam_engine.so")
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "slam_engine.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        s = os.path.join(HERE, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

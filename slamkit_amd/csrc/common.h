@@ -1,0 +1,72 @@
+// Common device helpers for the gfx950 (CDNA4) SpeechLM engine.
+// Wave = 64 lanes; all kernels here are written for gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define SLAM_DEVICE __device__ __forceinline__
+
+SLAM_DEVICE float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+SLAM_DEVICE bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+SLAM_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+SLAM_DEVICE void unpack_bf16x8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+SLAM_DEVICE uint4 pack_bf16x8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+  return v;
+}
+
+SLAM_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+SLAM_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// D[i][j] += sum_k A[i][k] * B[k][j], 16x16x32 bf16.
+//   a: lane l supplies A[i = l&15][k-block l>>4] (8 values)
+//   b: lane l supplies B[k-block l>>4][j = l&15] (8 values)
+//   d: lane l holds D[i = (l>>4)*4 + r][j = l&15], r = 0..3
+SLAM_DEVICE f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// LDS operand-tile layout shared by GEMM and attention: rows of 64 bf16 (128 B), eight
+// 16-byte chunks per row, chunk index XOR-swizzled with (row>>1)&7 so that the 16-lane groups
+// of a ds_read_b128 fragment read (16 consecutive rows, same chunk) hit 16 distinct slots.
+SLAM_DEVICE int lds_tile_off(int row, int chunk) {
+  return row * 128 + (((chunk) ^ ((row >> 1) & 7)) << 4);
+}
+
+#define HIP_CHECK_RET(expr)                                     \
+  do {                                                          \
+    hipError_t _e = (expr);                                     \
+    if (_e != hipSuccess) return (int)_e;                       \
+  } while (0)

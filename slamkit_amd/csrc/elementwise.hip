@@ -1,0 +1,612 @@
+// HBM-bound kernels of the Slam forward/backward/optimizer step for gfx950.
+// One wave64 per token row for the row-wise ops, 16-byte (bf16x8) accesses everywhere.
+// Reference semantics: site-packages transformers/models/qwen2/modeling_qwen2.py
+//   RMSNorm :247-252, RoPE :91-135, SwiGLU :41-48, embedding :356;
+// loss: /root/reference slamkit/model/unit_lm.py:13-29; optimizer: torch AdamW + HF
+// clip_grad_norm_.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks of 8 per lane -> hidden <= 2048
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm forward: y = bf16( x * rsqrt(mean(x^2)+eps) * w ), fp32 math, rstd saved.
+// Algorithmic traffic: 4 B/element (read bf16 + write bf16).
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd,
+                                                          int M, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = H >> 3;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * H);
+  uint4 v[MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+      v[i] = xr[c];
+      float f[8];
+      unpack_bf16x8(v[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)H + eps);
+  if (lane == 0 && rstd) rstd[row] = r;
+  uint4* yr = reinterpret_cast<uint4*>(y + (size_t)row * H);
+  const uint4* wr = reinterpret_cast<const uint4*>(w);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+      float f[8], g[8];
+      unpack_bf16x8(v[i], f);
+      unpack_bf16x8(wr[c], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = f[j] * r * g[j];
+      yr[c] = pack_bf16x8(f);
+    }
+  }
+}
+
+// RMSNorm backward. dx = rstd*(dy*w - xhat*mean(dy*w*xhat)) (+ dres); dw partial per block.
+// Each wave walks rows wave, wave+4*gridDim.. accumulating its dw slice in registers.
+// Algorithmic traffic: 6 B/element (+2 with the fused residual-gradient add).
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dres,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ dw_part,
+                                                          int M, int H) {
+  __shared__ float red[4][MAXC * 64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float dwa[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwa[i][j] = 0.f;
+  const uint4* wr = reinterpret_cast<const uint4*>(w);
+  float wv[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) unpack_bf16x8(wr[c], wv[i]);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * H);
+    const uint4* dyr = reinterpret_cast<const uint4*>(dy + (size_t)row * H);
+    const float r = rstd[row];
+    float xh[MAXC][8], gy[MAXC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+        float fx[8], fd[8];
+        unpack_bf16x8(xr[c], fx);
+        unpack_bf16x8(dyr[c], fd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = fx[j] * r;
+          gy[i][j] = fd[j] * wv[i][j];
+          dot += gy[i][j] * xh[i][j];
+          dwa[i][j] += fd[j] * xh[i][j];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)H;
+    uint4* dxr = reinterpret_cast<uint4*>(dx + (size_t)row * H);
+    const uint4* drr = dres ? reinterpret_cast<const uint4*>(dres + (size_t)row * H) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = r * (gy[i][j] - xh[i][j] * dot);
+        if (drr) {
+          float a[8];
+          unpack_bf16x8(drr[c], a);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += a[j];
+        }
+        dxr[c] = pack_bf16x8(o);
+      }
+    }
+  }
+  // cross-wave reduction of the dw partials, then one row of dw_part per block
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][(lane + 64 * i) * 8 + j] = dwa[i][j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < H; e += 256)
+    dw_part[(size_t)blockIdx.x * H + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
+
+// column sums of a bf16 matrix (bias gradient): part[block][N] fp32
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
+                                                          float* __restrict__ part) {
+  // each thread owns 8 columns of one chunk, loops rows blockIdx.y, +gridDim.y ...
+  int c = blockIdx.x * 256 + threadIdx.x;  // chunk index
+  if (c * 8 >= N) return;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = blockIdx.y; m < M; m += gridDim.y) {
+    float f[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += f[j];
+  }
+  float* o = part + (size_t)blockIdx.y * N + c * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = s[j];
+}
+
+// out[c] = (acc? out[c]:0) + sum_b part[b][c]
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out,
+                                     int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(size_t)b * N + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE tables (fp32 cos/sin [M][hd/2]) from positions; position_ids == nullptr -> m % T.
+__global__ void rope_table_kernel(const int64_t* __restrict__ pos, int M, int T, int half, float theta,
+                                  float* __restrict__ cs, float* __restrict__ sn) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * half) return;
+  int m = i / half, d = i % half;
+  float p = pos ? (float)pos[m] : (float)(m % T);
+  float inv = 1.0f / powf(theta, (float)(2 * d) / (float)(2 * half));
+  float a = p * inv;
+  float s, c;
+  sincosf(a, &s, &c);
+  cs[i] = c;
+  sn[i] = s;
+}
+
+// In-place rotate-half RoPE on the first `nrot` heads of each row of qkv [M][ld] (head_dim 64).
+// dir = +1 forward, -1 backward (transpose rotation).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, int M, int nrot,
+                                                   const float* __restrict__ cs, const float* __restrict__ sn,
+                                                   float dir) {
+  // one thread: 8 low-half elems + their 8 high-half partners of one head; 4 threads per head
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int per_row = nrot * 4;
+  if (idx >= M * per_row) return;
+  int m = idx / per_row, r = idx % per_row;
+  int head = r >> 2, part = r & 3;
+  bf16_t* base = qkv + (size_t)m * ld + head * 64 + part * 8;
+  uint4 lo = *reinterpret_cast<uint4*>(base), hi = *reinterpret_cast<uint4*>(base + 32);
+  float a[8], b[8], c[8], s[8];
+  unpack_bf16x8(lo, a);
+  unpack_bf16x8(hi, b);
+  const float4* cp = reinterpret_cast<const float4*>(cs + (size_t)m * 32 + part * 8);
+  const float4* sp = reinterpret_cast<const float4*>(sn + (size_t)m * 32 + part * 8);
+  *reinterpret_cast<float4*>(c) = cp[0]; *reinterpret_cast<float4*>(c + 4) = cp[1];
+  *reinterpret_cast<float4*>(s) = sp[0]; *reinterpret_cast<float4*>(s + 4) = sp[1];
+  float o1[8], o2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float sj = s[j] * dir;
+    o1[j] = a[j] * c[j] - b[j] * sj;
+    o2[j] = b[j] * c[j] + a[j] * sj;
+  }
+  *reinterpret_cast<uint4*>(base) = pack_bf16x8(o1);
+  *reinterpret_cast<uint4*>(base + 32) = pack_bf16x8(o2);
+}
+
+// ------------------------------------------------------------------------------------------
+// SwiGLU: gu [M][2I] (gate | up) -> act [M][I]
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                         size_t M, int I) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int nch = I >> 3;
+  if (idx >= M * nch) return;
+  size_t m = idx / nch;
+  int c = idx % nch;
+  const bf16_t* row = gu + m * 2 * I;
+  float g[8], u[8], o[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + c * 8), g);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + I + c * 8), u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+  *reinterpret_cast<uint4*>(act + m * I + c * 8) = pack_bf16x8(o);
+}
+
+// dgu (written in place over gu) from dact
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
+                                                         size_t M, int I) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int nch = I >> 3;
+  if (idx >= M * nch) return;
+  size_t m = idx / nch;
+  int c = idx % nch;
+  bf16_t* row = gu + m * 2 * I;
+  float g[8], u[8], d[8], dg[8], du[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + c * 8), g);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + I + c * 8), u);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(dact + m * I + c * 8), d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float sg = 1.f / (1.f + __expf(-g[j]));
+    float silu = g[j] * sg;
+    du[j] = d[j] * silu;
+    dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
+  }
+  *reinterpret_cast<uint4*>(row + c * 8) = pack_bf16x8(dg);
+  *reinterpret_cast<uint4*>(row + I + c * 8) = pack_bf16x8(du);
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding gather: out[m,:] = E[ids[m],:]
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids,
+                                                        const bf16_t* __restrict__ E, bf16_t* __restrict__ out,
+                                                        size_t M, int H, int V) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int nch = H >> 3;
+  if (idx >= M * nch) return;
+  size_t m = idx / nch;
+  int c = idx % nch;
+  int64_t id = ids[m];
+  if (id < 0 || id >= V) id = 0;
+  *reinterpret_cast<uint4*>(out + m * H + c * 8) = *reinterpret_cast<const uint4*>(E + (size_t)id * H + c * 8);
+}
+
+// One-hot rows for the gather-side embedding gradient (dE += onehot^T dh0 runs on the wgrad GEMM,
+// deterministic); the padding_idx column is suppressed like nn.Embedding(padding_idx).
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ ids, bf16_t* __restrict__ oh,
+                                                     size_t M, int Vp, int V, int pad_id) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int nch = Vp >> 3;
+  if (idx >= M * nch) return;
+  size_t m = idx / nch;
+  int c = idx % nch;
+  int64_t id = ids[m];
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (id >= 0 && id < V && id != pad_id && (id >> 3) == c) {
+    int j = (int)(id & 7);
+    w[j >> 1] = (j & 1) ? 0x3f800000u : 0x00003f80u;
+  }
+  *reinterpret_cast<uint4*>(oh + m * Vp + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Shifted cross-entropy over bf16 logits [M][Vp] (Vp = 512 padded, V valid columns).
+// target(m) = labels[m+1] when m is not the last position of its batch row, else ignore.
+__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int B, int T, double num_items,
+                                   float* __restrict__ denom) {
+  __shared__ int red[256];
+  int cnt = 0;
+  if (num_items <= 0.0) {
+    for (int i = threadIdx.x; i < B * T; i += 256) {
+      int t = i % T;
+      if (t < T - 1 && labels[i + 1] != -100) ++cnt;
+    }
+  }
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) denom[0] = num_items > 0.0 ? (float)num_items : (float)red[0];
+}
+
+// one wave per row, Vp == 512 (64 lanes x 8)
+__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits,
+                                                 const int64_t* __restrict__ labels,
+                                                 const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
+                                                 float* __restrict__ row_loss, int B, int T, int Vp, int V) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int M = B * T;
+  if (m >= M) return;
+  const int t = m % T;
+  int64_t tgt = (t < T - 1) ? labels[m + 1] : -100;
+  const bool valid = (tgt >= 0 && tgt < V);
+  uint4* dl = dlogits ? reinterpret_cast<uint4*>(dlogits + (size_t)m * Vp) + lane : nullptr;
+  if (!valid) {  // wave-uniform
+    if (dl) *dl = make_uint4(0, 0, 0, 0);
+    if (lane == 0) row_loss[m] = 0.f;
+    return;
+  }
+  float f[8];
+  unpack_bf16x8(reinterpret_cast<const uint4*>(logits + (size_t)m * Vp)[lane], f);
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (lane * 8 + j >= V) f[j] = -3.0e38f;
+    mx = fmaxf(mx, f[j]);
+  }
+  mx = wave_max(mx);
+  float e[8], s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    e[j] = (lane * 8 + j < V) ? __expf(f[j] - mx) : 0.f;
+    s += e[j];
+  }
+  s = wave_sum(s);
+  const float lse = mx + logf(s);
+  // logit of the target
+  float tl = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (lane * 8 + j == (int)tgt) tl = f[j];
+  tl = wave_sum(tl);
+  if (lane == 0) row_loss[m] = lse - tl;
+  if (dl) {
+    const float sc = 1.f / denom[0];
+    const float inv = 1.f / s;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float pj = e[j] * inv;
+      if (lane * 8 + j == (int)tgt) pj -= 1.f;
+      o[j] = pj * sc;
+    }
+    *dl = pack_bf16x8(o);
+  }
+}
+
+// loss = sum(row_loss) / denom  (single block, fixed order -> deterministic)
+__global__ void loss_finish_kernel(const float* __restrict__ row_loss, int M, const float* __restrict__ denom,
+                                   float* __restrict__ loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) s += (double)row_loss[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = denom[0] > 0.f ? (float)(red[0] / (double)denom[0]) : 0.f;
+}
+
+// Per-sequence sum of -row_loss over valid targets (log-likelihood, unit_lm.py:184-194 shape)
+__global__ void seq_loglik_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int B,
+                                  int T, float* __restrict__ ll, float* __restrict__ cnt) {
+  int b = blockIdx.x;
+  __shared__ float rs[256], rc[256];
+  float s = 0.f, c = 0.f;
+  for (int t = threadIdx.x; t < T - 1; t += 256) {
+    if (labels[(size_t)b * T + t + 1] != -100) { s -= row_loss[(size_t)b * T + t]; c += 1.f; }
+  }
+  rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) { rs[threadIdx.x] += rs[threadIdx.x + k]; rc[threadIdx.x] += rc[threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { ll[b] = rs[0]; cnt[b] = rc[0]; }
+}
+
+// strided 2-D bf16 copy in 16-byte chunks (padded logits -> user logits needs element copy; see below)
+__global__ __launch_bounds__(256) void copy_cols_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst,
+                                                        int ldd, size_t M, int ncols) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * (size_t)ncols) return;
+  size_t m = idx / ncols;
+  int c = idx % ncols;
+  dst[m * ldd + c] = src[m * lds_ + c];
+}
+
+__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x, size_t nchunks, float s) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  float f[8];
+  uint4* p = reinterpret_cast<uint4*>(x) + i;
+  unpack_bf16x8(*p, f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] *= s;
+  *p = pack_bf16x8(f);
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient norm (fp32 flat buffer) -> clip coefficient, and fused AdamW.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(g + i);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// out[0] = ||g||, out[1] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 when max_norm<=0)
+__global__ void norm_finish_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += (double)part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float nrm = (float)sqrt(red[0]);
+    out[0] = nrm;
+    float c = 1.f;
+    if (max_norm > 0.f) { c = max_norm / (nrm + 1e-6f); if (c > 1.f) c = 1.f; }
+    out[1] = c;
+  }
+}
+
+// torch.optim.AdamW semantics on fp32 master weights; writes the bf16 working copy; optional
+// grad zeroing. Traffic: 30 B/param (fp32 g,p,m,v read; p,m,v + bf16 written), 34 with zeroing.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_t* __restrict__ pb,
+                                                    float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n,
+                                                    const float* __restrict__ clip, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt,
+                                                    int zero_grad) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float cs = clip ? clip[1] : 1.f;
+  float4 gv = *reinterpret_cast<float4*>(g + i);
+  float4 pv = *reinterpret_cast<float4*>(p + i);
+  float4 mv = *reinterpret_cast<float4*>(m + i);
+  float4 vv = *reinterpret_cast<float4*>(v + i);
+  float ga[4] = {gv.x * cs, gv.y * cs, gv.z * cs, gv.w * cs};
+  float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+  const float step = lr / bc1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pa[j] *= (1.f - lr * wd);
+    ma[j] = b1 * ma[j] + (1.f - b1) * ga[j];
+    va[j] = b2 * va[j] + (1.f - b2) * ga[j] * ga[j];
+    float den = sqrtf(va[j]) / bc2_sqrt + eps;
+    pa[j] -= step * (ma[j] / den);
+  }
+  *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+  *reinterpret_cast<float4*>(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+  *reinterpret_cast<float4*>(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+  uint2 o;
+  o.x = pack_bf16x2(pa[0], pa[1]);
+  o.y = pack_bf16x2(pa[2], pa[3]);
+  *reinterpret_cast<uint2*>(pb + i) = o;
+  if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 v = *reinterpret_cast<const float4*>(s + i);
+  uint2 o;
+  o.x = pack_bf16x2(v.x, v.y);
+  o.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<uint2*>(d + i) = o;
+}
+
+inline unsigned nblocks(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+namespace slam {
+
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st) {
+  if ((H & 7) || H > MAXC * 512) return -1;
+  rmsnorm_fwd_kernel<<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps);
+  LAUNCH_RET();
+}
+
+int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }
+
+int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {
+  if ((H & 7) || H > MAXC * 512) return -1;
+  int nb = rmsnorm_bwd_blocks(M);
+  rmsnorm_bwd_kernel<<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);
+  colsum_finish_kernel<<<(H + 255) / 256, 256, 0, st>>>(part, nb, H, dw, accumulate);
+  LAUNCH_RET();
+}
+
+int colsum_blocks(int M) { int b = (M + 31) / 32; return b > 256 ? 256 : (b < 1 ? 1 : b); }
+
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st) {
+  if (N & 7) return -1;
+  int nb = colsum_blocks(M);
+  dim3 grid((N / 8 + 255) / 256, nb);
+  colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
+  colsum_finish_kernel<<<(N + 255) / 256, 256, 0, st>>>(part, nb, N, out, accumulate);
+  LAUNCH_RET();
+}
+
+int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st) {
+  int half = head_dim / 2;
+  rope_table_kernel<<<nblocks((size_t)M * half, 256), 256, 0, st>>>(pos, M, T, half, theta, cs, sn);
+  LAUNCH_RET();
+}
+
+int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, const float* sn, int backward, hipStream_t st) {
+  rope_kernel<<<nblocks((size_t)M * nrot_heads * 4, 256), 256, 0, st>>>(qkv, ld, M, nrot_heads, cs, sn, backward ? -1.f : 1.f);
+  LAUNCH_RET();
+}
+
+int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, hipStream_t st) {
+  if (I & 7) return -1;
+  swiglu_fwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, act, (size_t)M, I);
+  LAUNCH_RET();
+}
+int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, hipStream_t st) {
+  if (I & 7) return -1;
+  swiglu_bwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, dact, (size_t)M, I);
+  LAUNCH_RET();
+}
+
+int embed_fwd(const int64_t* ids, const bf16_t* E, bf16_t* out, int M, int H, int V, hipStream_t st) {
+  embed_fwd_kernel<<<nblocks((size_t)M * (H / 8), 256), 256, 0, st>>>(ids, E, out, (size_t)M, H, V);
+  LAUNCH_RET();
+}
+int onehot(const int64_t* ids, bf16_t* oh, int M, int Vp, int V, int pad_id, hipStream_t st) {
+  onehot_kernel<<<nblocks((size_t)M * (Vp / 8), 256), 256, 0, st>>>(ids, oh, (size_t)M, Vp, V, pad_id);
+  LAUNCH_RET();
+}
+
+int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
+                  float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st) {
+  if (Vp != 512) return -1;
+  int M = B * T;
+  count_valid_kernel<<<1, 256, 0, st>>>(labels, B, T, num_items, denom);
+  ce_kernel<<<(M + 3) / 4, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
+  loss_finish_kernel<<<1, 256, 0, st>>>(row_loss, M, denom, loss);
+  LAUNCH_RET();
+}
+int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float* ll, float* cnt, hipStream_t st) {
+  seq_loglik_kernel<<<B, 256, 0, st>>>(row_loss, labels, B, T, ll, cnt);
+  LAUNCH_RET();
+}
+int copy_cols(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int ncols, hipStream_t st) {
+  copy_cols_kernel<<<nblocks((size_t)M * ncols, 256), 256, 0, st>>>(src, lds_, dst, ldd, (size_t)M, ncols);
+  LAUNCH_RET();
+}
+int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st) {
+  if (n & 7) return -1;
+  scale_bf16_kernel<<<nblocks(n / 8, 256), 256, 0, st>>>(x, n / 8, s);
+  LAUNCH_RET();
+}
+
+int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st) {
+  if (n & 3) return -1;
+  int nb = 1024;
+  sumsq_partial_kernel<<<nb, 256, 0, st>>>(g, n, part);
+  norm_finish_kernel<<<1, 256, 0, st>>>(part, nb, max_norm, out);
+  LAUNCH_RET();
+}
+int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
+          double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
+  if (n & 3) return -1;
+  // bias corrections in double like torch.optim.AdamW (python floats), then fp32 in the kernel
+  float bc1 = (float)(1.0 - pow(b1, (double)step));
+  float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
+  adamw_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
+                                                     (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  LAUNCH_RET();
+}
+int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st) {
+  if (n & 3) return -1;
+  f32_to_bf16_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(s, d, n);
+  LAUNCH_RET();
+}
+
+}  // namespace slam

@@ -1,0 +1,455 @@
+// C ABI + step orchestration of the Slam engine (see include/slam_engine.h).
+// Replaces everything below UnitLM.forward / Trainer.training_step in the reference call stack
+// (SURVEY.md §3.1-3.2): Qwen2Model.forward (modeling_qwen2.py:342-402), the tied lm_head (:465),
+// compute_loss (unit_lm.py:13-29), autograd backward, clip_grad_norm_ and AdamW.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/slam_engine.h"
+#include "kernels.h"
+
+using namespace slam;
+
+namespace {
+
+constexpr int VPAD = 512;
+
+struct LayerOff {
+  int64_t ln1, wqkv, bqkv, wo, ln2, wgu, wd;
+};
+
+struct LayerAct {
+  bf16_t *hmid, *x1, *x2, *qkv, *o, *gu, *act;
+  float *rstd1, *rstd2, *lse;
+};
+
+__global__ void seg_fill_kernel(int* seg_start, int* seg_end, int M, int T) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int s = (m / T) * T;
+  seg_start[m] = s;
+  seg_end[m] = s + T;
+}
+
+}  // namespace
+
+struct SlamEngine {
+  SlamModelDesc d;
+  int QKV;  // (nH + 2 nKV) * hd
+  int64_t n_params;
+  int64_t off_embed, off_norm;
+  std::vector<LayerOff> lo;
+  std::vector<SlamTensorInfo> tensors;
+  std::string err;
+
+  bf16_t* params = nullptr;
+  float* grads = nullptr;
+
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t max_tokens = 0;
+  std::vector<bf16_t*> hs;  // L+1 residual streams
+  std::vector<LayerAct> la;
+  bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
+  float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
+  int *seg_s, *seg_e;
+
+  // last forward
+  int B = 0, T = 0;
+  bool have_fwd = false, have_loss = false;
+  const int64_t* last_ids = nullptr;
+  const int* cur_seg_s = nullptr;
+  const int* cur_seg_e = nullptr;
+
+  int fail(int code, const std::string& m) {
+    err = m;
+    return code;
+  }
+};
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+size_t max_gemm_ws(const SlamEngine* e, int M) {
+  const SlamModelDesc& d = e->d;
+  size_t w = 0;
+  auto upd = [&](int N, int K) { size_t b = gemm_tn_workspace_bytes(M, N, K); if (b > w) w = b; };
+  upd(e->QKV, d.hidden);
+  upd(d.hidden, d.n_heads * d.head_dim);
+  upd(2 * d.intermediate, d.hidden);
+  upd(d.hidden, d.intermediate);
+  upd(VPAD, d.hidden);
+  return w;
+}
+
+size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
+  const SlamModelDesc& d = e->d;
+  const size_t M = (size_t)Mmax, H = d.hidden, I = d.intermediate, L = d.n_layers;
+  Carver c{base};
+  e->hs.resize(L + 1);
+  e->la.resize(L);
+  for (size_t l = 0; l <= L; ++l) e->hs[l] = c.take<bf16_t>(M * H);
+  for (size_t l = 0; l < L; ++l) {
+    LayerAct& a = e->la[l];
+    a.hmid = c.take<bf16_t>(M * H);
+    a.x1 = c.take<bf16_t>(M * H);
+    a.x2 = c.take<bf16_t>(M * H);
+    a.qkv = c.take<bf16_t>(M * e->QKV);
+    a.o = c.take<bf16_t>(M * d.n_heads * d.head_dim);
+    a.gu = c.take<bf16_t>(M * 2 * I);
+    a.act = c.take<bf16_t>(M * I);
+    a.rstd1 = c.take<float>(M);
+    a.rstd2 = c.take<float>(M);
+    a.lse = c.take<float>(M * d.n_heads);
+  }
+  e->hf = c.take<bf16_t>(M * H);
+  e->rstdf = c.take<float>(M);
+  e->logits = c.take<bf16_t>(M * VPAD);
+  e->dlogits = c.take<bf16_t>(M * VPAD);
+  e->onehot = c.take<bf16_t>(M * VPAD);
+  e->row_loss = c.take<float>(M);
+  e->dh_a = c.take<bf16_t>(M * H);
+  e->dh_b = c.take<bf16_t>(M * H);
+  e->dx = c.take<bf16_t>(M * H);
+  e->dact = c.take<bf16_t>(M * I);
+  e->dqkv = c.take<bf16_t>(M * e->QKV);
+  e->d_o = c.take<bf16_t>(M * d.n_heads * d.head_dim);
+  e->dsum = c.take<float>(M * d.n_heads);
+  e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_heads) / sizeof(float));
+  e->cosb = c.take<float>(M * (d.head_dim / 2));
+  e->sinb = c.take<float>(M * (d.head_dim / 2));
+  e->seg_s = c.take<int>(M);
+  e->seg_e = c.take<int>(M);
+  e->gemm_ws = c.take<float>(max_gemm_ws(e, (int)M) / sizeof(float));
+  size_t part = (size_t)rmsnorm_bwd_blocks((int)M) * H;
+  size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
+  if (part2 > part) part = part2;
+  if (part < 1024) part = 1024;
+  e->part_ws = c.take<float>(part);
+  e->scal = c.take<float>(64);
+  return (c.off + 255) & ~(size_t)255;
+}
+
+void add_tensor(SlamEngine* e, const std::string& name, int64_t& off, int64_t rows, int64_t cols) {
+  SlamTensorInfo t;
+  memset(&t, 0, sizeof(t));
+  snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+  t.offset = off;
+  t.rows = rows;
+  t.cols = cols;
+  e->tensors.push_back(t);
+  off += rows * cols;
+}
+
+#define CK(expr)                                                                     \
+  do {                                                                               \
+    int _r = (expr);                                                                 \
+    if (_r != 0) {                                                                   \
+      char _b[256];                                                                  \
+      snprintf(_b, sizeof(_b), "%s failed with %d (%s) at %s:%d", #expr, _r,         \
+               _r > 0 ? hipGetErrorString((hipError_t)_r) : "engine", __FILE__, __LINE__); \
+      return h->fail(_r, _b);                                                        \
+    }                                                                                \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* slam_version(void) { return "slam-engine gfx950 r1"; }
+
+int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
+  if (!desc || !out) return SLAM_EINVAL;
+  const SlamModelDesc& d = *desc;
+  if (d.head_dim != 64 || d.n_heads <= 0 || d.n_kv_heads <= 0 || d.n_heads % d.n_kv_heads) return SLAM_EINVAL;
+  if (d.hidden % 8 || d.hidden > 2048 || d.intermediate % 8 || d.vocab <= 0 || d.vocab > VPAD) return SLAM_EINVAL;
+  if (d.n_layers <= 0) return SLAM_EINVAL;
+  SlamEngine* e = new SlamEngine();
+  e->d = d;
+  e->QKV = (d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
+  int64_t off = 0;
+  e->off_embed = off;
+  add_tensor(e, "embed", off, VPAD, d.hidden);
+  e->lo.resize(d.n_layers);
+  for (int l = 0; l < d.n_layers; ++l) {
+    std::string p = "layers." + std::to_string(l) + ".";
+    LayerOff& o = e->lo[l];
+    o.ln1 = off;  add_tensor(e, p + "ln1", off, d.hidden, 1);
+    o.wqkv = off; add_tensor(e, p + "wqkv", off, e->QKV, d.hidden);
+    o.bqkv = off; add_tensor(e, p + "bqkv", off, e->QKV, 1);
+    o.wo = off;   add_tensor(e, p + "wo", off, d.hidden, d.n_heads * d.head_dim);
+    o.ln2 = off;  add_tensor(e, p + "ln2", off, d.hidden, 1);
+    o.wgu = off;  add_tensor(e, p + "wgu", off, 2 * d.intermediate, d.hidden);
+    o.wd = off;   add_tensor(e, p + "wd", off, d.hidden, d.intermediate);
+  }
+  e->off_norm = off;
+  add_tensor(e, "norm", off, d.hidden, 1);
+  e->n_params = off;
+  *out = e;
+  return SLAM_OK;
+}
+
+void slam_engine_destroy(SlamEngine* h) { delete h; }
+const char* slam_last_error(SlamEngine* h) { return h ? h->err.c_str() : "null engine"; }
+int64_t slam_param_count(SlamEngine* h) { return h ? h->n_params : 0; }
+int32_t slam_tensor_count(SlamEngine* h) { return h ? (int32_t)h->tensors.size() : 0; }
+int slam_tensor_info(SlamEngine* h, int32_t i, SlamTensorInfo* out) {
+  if (!h || !out || i < 0 || i >= (int32_t)h->tensors.size()) return SLAM_EINVAL;
+  *out = h->tensors[i];
+  return SLAM_OK;
+}
+int slam_bind_params(SlamEngine* h, void* params_bf16, float* grads_f32) {
+  if (!h || !params_bf16) return SLAM_EINVAL;
+  h->params = (bf16_t*)params_bf16;
+  h->grads = grads_f32;
+  return SLAM_OK;
+}
+size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens) {
+  if (!h || max_tokens <= 0) return 0;
+  SlamEngine tmp;
+  tmp.d = h->d;
+  tmp.QKV = h->QKV;
+  return carve(&tmp, nullptr, max_tokens);
+}
+int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_tokens) {
+  if (!h || !ws || max_tokens <= 0) return SLAM_EINVAL;
+  if (((uintptr_t)ws) & 255) return h->fail(SLAM_EINVAL, "workspace must be 256-byte aligned");
+  size_t need = slam_workspace_bytes(h, max_tokens);
+  if (bytes < need) return h->fail(SLAM_ENOMEM, "workspace too small");
+  carve(h, (char*)ws, max_tokens);
+  h->ws = (char*)ws;
+  h->ws_bytes = bytes;
+  h->max_tokens = max_tokens;
+  h->have_fwd = false;
+  return SLAM_OK;
+}
+int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
+  if (!key) return SLAM_EINVAL;
+  if (!strcmp(key, "gemm_glds")) { gemm_set_glds((int)value); return SLAM_OK; }
+  return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
+}
+
+int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const int64_t* position_ids,
+                 const int32_t* seg_start, const int32_t* seg_end, int32_t B, int32_t T, double num_items,
+                 float* loss_out, void* logits_out, slam_stream_t stream) {
+  if (!h || !ids || B <= 0 || T <= 0) return SLAM_EINVAL;
+  if (!h->params || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");
+  const int64_t M64 = (int64_t)B * T;
+  if (M64 > h->max_tokens) return h->fail(SLAM_ENOMEM, "B*T exceeds bound workspace tokens");
+  if ((seg_start == nullptr) != (seg_end == nullptr)) return h->fail(SLAM_EINVAL, "seg_start/seg_end both or none");
+  if (labels && !loss_out) return h->fail(SLAM_EINVAL, "labels given without loss_out");
+  const int M = (int)M64;
+  const SlamModelDesc& d = h->d;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
+  const bf16_t* P = h->params;
+  h->have_fwd = false;
+
+  if (seg_start) {
+    h->cur_seg_s = seg_start;
+    h->cur_seg_e = seg_end;
+  } else {
+    seg_fill_kernel<<<(M + 255) / 256, 256, 0, st>>>(h->seg_s, h->seg_e, M, T);
+    h->cur_seg_s = h->seg_s;
+    h->cur_seg_e = h->seg_e;
+  }
+  CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
+  CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
+  for (int l = 0; l < L; ++l) {
+    const LayerOff& o = h->lo[l];
+    LayerAct& a = h->la[l];
+    CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
+    CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
+    CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 0, st));
+    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, M, nH, nKV, d.head_dim, st));
+    CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
+    CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
+    CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
+    CK(swiglu_fwd(a.gu, a.act, M, I, st));
+    CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
+  }
+  CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
+  CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VPAD, H, st));
+  h->have_loss = false;
+  if (labels) {
+    CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VPAD,
+                     d.vocab, st));
+    CK((int)hipMemcpyAsync(loss_out, h->scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    h->have_loss = true;
+  }
+  if (logits_out) CK(copy_cols(h->logits, VPAD, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
+  h->B = B;
+  h->T = T;
+  h->last_ids = ids;
+  h->have_fwd = true;
+  return SLAM_OK;
+}
+
+int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_bucket_cb cb, void* user,
+                  slam_stream_t stream) {
+  if (!h) return SLAM_EINVAL;
+  if (!h->have_fwd || !h->have_loss) return h->fail(SLAM_ESTATE, "backward needs a forward with labels");
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  const SlamModelDesc& d = h->d;
+  hipStream_t st = (hipStream_t)stream;
+  const int M = h->B * h->T;
+  const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
+  const int HD = nH * d.head_dim;
+  const bf16_t* P = h->params;
+  float* G = h->grads;
+
+  if (grad_scale != 1.0f) CK(scale_bf16(h->dlogits, (size_t)M * VPAD, grad_scale, st));
+  // tied head: dE += dlogits^T hf ; dhf = dlogits E
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, 1, M, VPAD, H, VPAD, H, h->gemm_ws, st));
+  CK(gemm_nn(h->dlogits, P + h->off_embed, h->dx, nullptr, M, VPAD, H, st));
+  bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
+  bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
+  CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, 1, h->part_ws, M, H, st));
+
+  const int bl = bucket_layers > 0 ? bucket_layers : L;
+  int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerOff& o = h->lo[l];
+    LayerAct& a = h->la[l];
+    // MLP
+    CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
+    CK(gemm_nn(dh, P + o.wd, h->dact, nullptr, M, H, I, st));
+    CK(swiglu_bwd(a.gu, h->dact, M, I, st));  // a.gu now holds d(gate|up)
+    CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
+    CK(gemm_nn(a.gu, P + o.wgu, h->dx, nullptr, M, 2 * I, H, st));
+    CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, G + o.ln2, 1, h->part_ws, M, H, st));
+    // attention
+    CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
+    CK(gemm_nn(dh2, P + o.wo, h->d_o, nullptr, M, H, HD, st));
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, M, nH, nKV,
+                d.head_dim, st));
+    CK(rope_apply(h->dqkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 1, st));
+    CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, G + o.bqkv, 1, h->part_ws, st));
+    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
+    CK(gemm_nn(h->dqkv, P + o.wqkv, h->dx, nullptr, M, h->QKV, H, st));
+    CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, G + o.ln1, 1, h->part_ws, M, H, st));
+    if (cb && l > 0 && ((L - l) % bl) == 0) {
+      cb(user, o.ln1, bucket_end - o.ln1);
+      bucket_end = o.ln1;
+    }
+  }
+  // gather-side embedding gradient: dE += onehot(ids)^T dh0 (padding_idx column suppressed)
+  CK(onehot(h->last_ids, h->onehot, M, VPAD, d.vocab, d.pad_token_id, st));
+  CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VPAD, H, VPAD, H, h->gemm_ws, st));
+  if (cb) cb(user, 0, bucket_end);
+  h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
+  return SLAM_OK;
+}
+
+int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, float* ll_out, float* cnt_out,
+                    slam_stream_t stream) {
+  if (!h || !labels || !ll_out || !cnt_out) return SLAM_EINVAL;
+  if (!h->have_fwd || B != h->B || T != h->T) return h->fail(SLAM_ESTATE, "seq_loglik needs the matching forward");
+  CK(seq_loglik(h->row_loss, labels, B, T, ll_out, cnt_out, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream) {
+  if (!h || !norm_out) return SLAM_EINVAL;
+  if (!h->grads || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");
+  CK(grad_norm(h->grads, (size_t)h->n_params, max_norm, h->part_ws, norm_out, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const float* norm_out, double lr, double b1,
+                    double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
+  if (!h || !master || !m || !v || step < 1) return SLAM_EINVAL;
+  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad,
+           (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+int slam_zero_grads(SlamEngine* h, slam_stream_t stream) {
+  if (!h || !h->grads) return SLAM_EINVAL;
+  CK((int)hipMemsetAsync(h->grads, 0, (size_t)h->n_params * sizeof(float), (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+int slam_cast_params(SlamEngine* h, const float* master, slam_stream_t stream) {
+  if (!h || !master || !h->params) return SLAM_EINVAL;
+  CK(f32_to_bf16(master, h->params, (size_t)h->n_params, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+// ---- single-op entry points ------------------------------------------------------------------
+int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
+                    int use_glds, slam_stream_t s) {
+  gemm_set_glds(use_glds);
+  int r = gemm_nt((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (const bf16_t*)bias, (const bf16_t*)resid, M, N, K,
+                  (hipStream_t)s);
+  gemm_set_glds(1);
+  return r;
+}
+int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s) {
+  return gemm_nn((const bf16_t*)dY, (const bf16_t*)W, (bf16_t*)dX, (const bf16_t*)resid, M, N, K, (hipStream_t)s);
+}
+size_t slam_op_gemm_tn_workspace(int M, int N, int K) { return gemm_tn_workspace_bytes(M, N, K); }
+int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,
+                    slam_stream_t s) {
+  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, (hipStream_t)s);
+}
+int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s) {
+  return rmsnorm_fwd((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, M, H, eps, (hipStream_t)s);
+}
+size_t slam_op_rmsnorm_bwd_workspace(int M, int H) { return (size_t)rmsnorm_bwd_blocks(M) * H * sizeof(float); }
+int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                        float* dw, float* ws, int M, int H, slam_stream_t s) {
+  return rmsnorm_bwd((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw,
+                     0, ws, M, H, (hipStream_t)s);
+}
+int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, const int64_t* position_ids, float theta,
+                 int backward, float* cs_ws, slam_stream_t s) {
+  int r = rope_table(position_ids, M, T, 64, theta, cs_ws, cs_ws + (size_t)M * 32, (hipStream_t)s);
+  if (r) return r;
+  return rope_apply((bf16_t*)qkv, ld, M, n_rot_heads, cs_ws, cs_ws + (size_t)M * 32, backward, (hipStream_t)s);
+}
+int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s) {
+  return swiglu_fwd((const bf16_t*)gu, (bf16_t*)act, M, I, (hipStream_t)s);
+}
+int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s) {
+  return swiglu_bwd((bf16_t*)gu, (const bf16_t*)dact, M, I, (hipStream_t)s);
+}
+int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
+                     slam_stream_t s) {
+  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, M, nH, nKV, 64, (hipStream_t)s);
+}
+size_t slam_op_attn_bwd_workspace(int M, int nH) {
+  return attn_bwd_workspace_bytes(M, nH) + (size_t)M * nH * sizeof(float);
+}
+int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
+                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, slam_stream_t s) {
+  float* dsum = ws;
+  float* part = ws + (size_t)M * nH;
+  return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, dsum, (bf16_t*)dqkv, part, seg_start,
+                  seg_end, M, nH, nKV, 64, (hipStream_t)s);
+}
+int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
+                          float* scratch2, int B, int T, int V, slam_stream_t s) {
+  return cross_entropy((const bf16_t*)logits, labels, num_items, (bf16_t*)dlogits, row_loss, scratch2, scratch2 + 1, B,
+                       T, VPAD, V, (hipStream_t)s);
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// Internal launcher declarations shared by the engine translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+namespace slam {
+
+// gemm.hip
+void gemm_set_glds(int on);
+int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
+            int K, hipStream_t st);
+int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
+            hipStream_t st);
+int gemm_tn_splits(int M, int N, int K);
+size_t gemm_tn_workspace_bytes(int M, int N, int K);
+int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
+            float* ws, hipStream_t st);
+
+// attention.hip
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, int M, int nH, int nKV, int head_dim,
+             hipStream_t st);
+size_t attn_bwd_workspace_bytes(int M, int nH);
+int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum, bf16_t* dqkv,
+             float* dkv_part, const int* seg_start, const int* seg_end, int M, int nH, int nKV, int head_dim,
+             hipStream_t st);
+
+// elementwise.hip
+int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
+int rmsnorm_bwd_blocks(int M);
+int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st);
+int colsum_blocks(int M);
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st);
+int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st);
+int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, const float* sn, int backward,
+               hipStream_t st);
+int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, hipStream_t st);
+int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, hipStream_t st);
+int embed_fwd(const int64_t* ids, const bf16_t* E, bf16_t* out, int M, int H, int V, hipStream_t st);
+int onehot(const int64_t* ids, bf16_t* oh, int M, int Vp, int V, int pad_id, hipStream_t st);
+int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
+                  float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st);
+int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float* ll, float* cnt, hipStream_t st);
+int copy_cols(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int ncols, hipStream_t st);
+int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st);
+int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st);
+int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
+          double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
+int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st);
+
+}  // namespace slam

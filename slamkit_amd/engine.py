@@ -1,0 +1,211 @@
+"""ctypes binding of libslam_engine.so (include/slam_engine.h).
+
+PyTorch-ROCm is plumbing here: it owns device memory and streams; every compute call goes
+through the C ABI with raw device pointers. There is NO CPU or eager fallback: if the HIP
+library is missing the import of :func:`load_library` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libslam_engine.so")
+_lib = None
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
+
+
+class SlamModelDesc(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("hidden", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("intermediate", C.c_int32), ("vocab", C.c_int32), ("pad_token_id", C.c_int32),
+        ("rms_eps", C.c_float), ("rope_theta", C.c_float),
+    ]
+
+
+class SlamTensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("offset", C.c_int64), ("rows", C.c_int64), ("cols", C.c_int64)]
+
+
+def header_symbols() -> List[str]:
+    """Every function name declared in include/slam_engine.h (used by the export test)."""
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "slam_engine.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", txt)) - {"slam_bucket_cb"})
+
+
+def load_library(path: Optional[str] = None):
+    """Load the HIP engine; raises OSError (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("SLAM_ENGINE_LIB", _LIB_PATH)
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `python -m slamkit_amd.csrc.build` "
+                      f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+    sig = {
+        "slam_engine_create": (C.c_int, [C.POINTER(SlamModelDesc), C.POINTER(vp)]),
+        "slam_engine_destroy": (None, [vp]),
+        "slam_last_error": (C.c_char_p, [vp]),
+        "slam_version": (C.c_char_p, []),
+        "slam_param_count": (i64, [vp]),
+        "slam_tensor_count": (i32, [vp]),
+        "slam_tensor_info": (C.c_int, [vp, i32, C.POINTER(SlamTensorInfo)]),
+        "slam_bind_params": (C.c_int, [vp, vp, vp]),
+        "slam_workspace_bytes": (sz, [vp, i64]),
+        "slam_bind_workspace": (C.c_int, [vp, vp, sz, i64]),
+        "slam_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
+        "slam_backward": (C.c_int, [vp, f32, i32, BUCKET_CB, vp, vp]),
+        "slam_seq_loglik": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+        "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
+        "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_zero_grads": (C.c_int, [vp, vp]),
+        "slam_cast_params": (C.c_int, [vp, vp, vp]),
+        "slam_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "slam_op_gemm_nt": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_gemm_nn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_gemm_tn_workspace": (sz, [C.c_int, C.c_int, C.c_int]),
+        "slam_op_gemm_tn": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "slam_op_rmsnorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
+        "slam_op_rmsnorm_bwd_workspace": (sz, [C.c_int, C.c_int]),
+        "slam_op_rmsnorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+        "slam_op_rope": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, C.c_int, vp, vp]),
+        "slam_op_swiglu_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+        "slam_op_swiglu_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+        "slam_op_attn_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_attn_bwd_workspace": (sz, [C.c_int, C.c_int]),
+        "slam_op_attn_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_cross_entropy": (C.c_int, [vp, vp, f64, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._slam_signatures = sig
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(t) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+@dataclass
+class TensorSpec:
+    name: str
+    offset: int
+    rows: int
+    cols: int
+
+    @property
+    def numel(self) -> int:
+        return self.rows * self.cols
+
+
+class Engine:
+    """Thin owner of a SlamEngine handle plus the torch tensors it borrows."""
+
+    def __init__(self, desc: SlamModelDesc):
+        self.lib = load_library()
+        self.desc = desc
+        h = C.c_void_p()
+        rc = self.lib.slam_engine_create(C.byref(desc), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"slam_engine_create failed ({rc}): unsupported model description")
+        self.h = h
+        self.n_params = int(self.lib.slam_param_count(h))
+        self.tensors: Dict[str, TensorSpec] = {}
+        info = SlamTensorInfo()
+        for i in range(self.lib.slam_tensor_count(h)):
+            self._ck(self.lib.slam_tensor_info(h, i, C.byref(info)))
+            self.tensors[info.name.decode()] = TensorSpec(info.name.decode(), info.offset, info.rows, info.cols)
+        self._keep = {}
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            msg = self.lib.slam_last_error(self.h)
+            raise EngineError(f"engine call failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slam_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- binding ------------------------------------------------------------------------------
+    def bind_params(self, params_bf16, grads_f32=None):
+        import torch
+        assert params_bf16.dtype == torch.bfloat16 and params_bf16.numel() == self.n_params and params_bf16.is_cuda
+        if grads_f32 is not None:
+            assert grads_f32.dtype == torch.float32 and grads_f32.numel() == self.n_params
+        self._keep["params"], self._keep["grads"] = params_bf16, grads_f32
+        self._ck(self.lib.slam_bind_params(self.h, _ptr(params_bf16), _ptr(grads_f32)))
+
+    def workspace_bytes(self, max_tokens: int) -> int:
+        return int(self.lib.slam_workspace_bytes(self.h, max_tokens))
+
+    def bind_workspace(self, ws, max_tokens: int):
+        self._keep["ws"] = ws
+        self._ck(self.lib.slam_bind_workspace(self.h, _ptr(ws), ws.numel() * ws.element_size(), max_tokens))
+
+    def set_option(self, key: str, value: int):
+        self._ck(self.lib.slam_set_option(self.h, key.encode(), int(value)))
+
+    # -- step ---------------------------------------------------------------------------------
+    def forward(self, ids, labels=None, position_ids=None, seg_start=None, seg_end=None, B=1, T=1,
+                num_items: float = 0.0, loss_out=None, logits_out=None, stream: Optional[int] = None):
+        self._ck(self.lib.slam_forward(self.h, _ptr(ids), _ptr(labels), _ptr(position_ids), _ptr(seg_start),
+                                       _ptr(seg_end), B, T, float(num_items), _ptr(loss_out), _ptr(logits_out),
+                                       stream if stream is not None else current_stream_ptr()))
+
+    def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0,
+                 bucket_cb: Optional[Callable[[int, int], None]] = None, stream: Optional[int] = None):
+        if bucket_cb is None:
+            cb = C.cast(None, BUCKET_CB)
+        else:
+            cb = BUCKET_CB(lambda _u, off, cnt: bucket_cb(int(off), int(cnt)))
+        self._ck(self.lib.slam_backward(self.h, float(grad_scale), int(bucket_layers), cb, None,
+                                        stream if stream is not None else current_stream_ptr()))
+
+    def seq_loglik(self, labels, B, T, ll_out, cnt_out, stream=None):
+        self._ck(self.lib.slam_seq_loglik(self.h, _ptr(labels), B, T, _ptr(ll_out), _ptr(cnt_out),
+                                          stream if stream is not None else current_stream_ptr()))
+
+    def grad_norm(self, max_norm: float, norm_out, stream=None):
+        self._ck(self.lib.slam_grad_norm(self.h, float(max_norm), _ptr(norm_out),
+                                         stream if stream is not None else current_stream_ptr()))
+
+    def adamw_step(self, master, exp_avg, exp_avg_sq, norm_out, lr, beta1, beta2, eps, weight_decay, step,
+                   zero_grad=True, stream=None):
+        self._ck(self.lib.slam_adamw_step(self.h, _ptr(master), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(norm_out),
+                                          float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                          int(step), int(bool(zero_grad)),
+                                          stream if stream is not None else current_stream_ptr()))
+
+    def zero_grads(self, stream=None):
+        self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))
+
+    def cast_params(self, master, stream=None):
+        self._ck(self.lib.slam_cast_params(self.h, _ptr(master),
+                                           stream if stream is not None else current_stream_ptr()))

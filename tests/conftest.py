@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_npz():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "tiny_model.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_data():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "data.json")))

@@ -1,0 +1,146 @@
+"""The CPU oracle against the golden vectors captured from the real reference
+(tests/golden/make_golden.py). fp32 tolerances from SURVEY.md §8c: logits <= 1e-5 abs,
+loss <= 1e-6, grads <= 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_oracle as O
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_data):
+    meta = golden_data["meta"]
+    cfg = O.OracleConfig(**meta["config"])
+    sd = O.init_weights(cfg, seed=meta["seed"], bias_std=meta["bias_std"], norm_jitter=meta["norm_jitter"])
+    return cfg, sd
+
+
+def test_tokeniser_known_answers(golden_data):
+    # the reference's own known-answer pair: example_data/features.jsonl -> tokens.jsonl (README.md:35,48,65)
+    assert golden_data["vocab_size"] == len(O.unit_vocab()) == 502
+    for row in golden_data["G1_tokens"]:
+        assert O.stringify_units(row["units"]) == row["audio_repr"]
+        enc = O.unit_tokenise(row["audio_repr"])
+        assert enc["input_ids"] == row["input_ids"] == [1] + [u + 2 for u in row["units"]] + [1]
+        assert enc["attention_mask"] == row["attention_mask"]
+    assert [len(r["input_ids"]) for r in golden_data["G1_tokens"]] == [330, 290]
+
+
+def test_chunk_texts(golden_data):
+    ex = {"input_ids": [g["input_ids"] for g in golden_data["G1_tokens"]],
+          "attention_mask": [g["attention_mask"] for g in golden_data["G1_tokens"]]}
+    for c, exp in golden_data["G2_chunks"].items():
+        assert O.chunk_texts(ex, int(c)) == exp
+    assert [len(x) for x in O.chunk_texts(ex, 128)["input_ids"]] == [128, 128, 74, 128, 128, 34]
+
+
+def test_collators(golden_data):
+    ex = {"input_ids": [g["input_ids"] for g in golden_data["G1_tokens"]],
+          "attention_mask": [g["attention_mask"] for g in golden_data["G1_tokens"]]}
+    ch = O.chunk_texts(ex, 128)
+    feats = [{"input_ids": a, "attention_mask": b} for a, b in zip(ch["input_ids"], ch["attention_mask"])][1:4]
+    lm = O.collate_lm(feats)
+    for k, v in golden_data["G3_lm"].items():
+        assert lm[k].tolist() == v, k
+    fl = O.collate_flatten(feats)
+    for k in ("input_ids", "position_ids", "labels"):
+        assert fl[k].tolist() == golden_data["G3_flat"][k], k
+
+
+def test_padded_forward_loss(tiny, golden_npz):
+    cfg, sd = tiny
+    g = golden_npz
+    ids, am, lab = (torch.from_numpy(g[k]) for k in ("pad_ids", "pad_mask", "pad_labels"))
+    with torch.no_grad():
+        logits = O.model_forward(cfg, sd, ids, attention_mask=am)
+    valid = am.bool()
+    assert (logits[valid] - torch.from_numpy(g["pad_logits"])[valid]).abs().max() <= 1e-5
+    assert abs(float(O.compute_loss(logits, lab)) - float(g["pad_loss_mean"])) <= 1e-6
+    n = int(g["pad_num_items"])
+    assert n == O.get_num_tokens(lab)
+    assert abs(float(O.compute_loss(logits, lab, num_items_in_batch=n)) - float(g["pad_loss_sum"])) <= 1e-6
+
+
+def test_padded_grads(tiny, golden_npz):
+    cfg, sd = tiny
+    g = golden_npz
+    ids, am, lab = (torch.from_numpy(g[k]) for k in ("pad_ids", "pad_mask", "pad_labels"))
+    loss, _, grads = O.forward_loss_grads(cfg, sd, ids, lab, attention_mask=am)
+    assert abs(float(loss) - float(g["pad_loss_mean"])) <= 1e-6
+    for k, gr in grads.items():
+        ref_norm = float(g["pad_gradnorm/" + k])
+        assert abs(float(gr.norm()) - ref_norm) <= 1e-5 * max(ref_norm, 1e-3), k
+        flat = gr.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        assert np.allclose(flat[idx].numpy(), g["pad_gradsample/" + k], rtol=1e-4, atol=1e-7), k
+    for key in [k for k in g if k.startswith("pad_gradfull/")]:
+        name = key.split("/", 1)[1]
+        ref = torch.from_numpy(g[key])
+        assert (grads[name] - ref).norm() <= 1e-5 * ref.norm() + 1e-9, name
+    # padding_idx row: only the tied-head contribution remains, and it is non-zero
+    assert float(grads["lm.model.embed_tokens.weight"][0].abs().sum()) > 0
+
+
+def test_packed_forward_matches_per_sequence_reference(tiny, golden_npz):
+    # the reference's packed path needs flash-attn varlen; its semantics = each sequence alone
+    cfg, sd = tiny
+    g = golden_npz
+    assert float(g["pack_direct_maxdiff"]) > 1e-2  # sdpa reference ignores packing -> stitched vectors are the truth
+    ids, pos, lab = (torch.from_numpy(g[k]) for k in ("pack_ids", "pack_pos", "pack_labels"))
+    with torch.no_grad():
+        logits = O.model_forward(cfg, sd, ids, position_ids=pos, packed=True)
+    assert (logits - torch.from_numpy(g["pack_logits"])).abs().max() <= 1e-5
+    assert abs(float(O.compute_loss(logits, lab)) - float(g["pack_loss_mean"])) <= 1e-6
+
+
+def test_log_likelihood(tiny, golden_npz):
+    cfg, sd = tiny
+    ids = torch.from_numpy(golden_npz["pad_ids"])
+    for mean_nll, key in ((True, "ll_mean"), (False, "ll_sum")):
+        ll = O.log_likelihood(cfg, sd, ids.clone(), mean_nll)
+        assert np.allclose(ll.numpy(), golden_npz[key], rtol=1e-5, atol=1e-4), key
+
+
+def test_schedule_and_adamw_match_torch():
+    # cosine_with_min_lr (config/training_args/default.yaml:4-7: lr 1e-3, min 5e-5, warmup 100)
+    r = 5e-5 / 1e-3
+    assert O.cosine_with_min_lr(0, 100, 1000, r) == 0.0
+    assert abs(O.cosine_with_min_lr(50, 100, 1000, r) - 0.5) < 1e-12
+    assert abs(O.cosine_with_min_lr(100, 100, 1000, r) - 1.0) < 1e-12
+    assert abs(O.cosine_with_min_lr(1000, 100, 1000, r) - r) < 1e-12
+    assert abs(O.cosine_with_min_lr(550, 100, 1000, r) - (0.5 * (1 - r) + r)) < 1e-12
+    from transformers.optimization import get_scheduler
+    p = torch.nn.Parameter(torch.randn(7, 5))
+    opt = torch.optim.AdamW([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    sch = get_scheduler("cosine_with_min_lr", opt, num_warmup_steps=10, num_training_steps=60,
+                        scheduler_specific_kwargs={"min_lr": 5e-5})
+    q, m, v = p.detach().clone(), torch.zeros(7, 5), torch.zeros(7, 5)
+    gen = torch.Generator().manual_seed(0)
+    for step in range(1, 31):
+        g = torch.randn(7, 5, generator=gen)
+        lr_ref = sch.get_last_lr()[0]
+        lr = 1e-3 * O.cosine_with_min_lr(step - 1, 10, 60, 5e-5 / 1e-3)
+        assert abs(lr - lr_ref) < 1e-12
+        p.grad = g.clone()
+        opt.step()
+        sch.step()
+        O.adamw_update(q, g, m, v, step, lr)
+        assert torch.allclose(q, p.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_clip_coef_matches_torch():
+    gs = {"a": torch.randn(10, 3), "b": torch.randn(5)}
+    ps = [torch.nn.Parameter(torch.zeros_like(g)) for g in gs.values()]
+    for p, g in zip(ps, gs.values()):
+        p.grad = g.clone()
+    tot = torch.nn.utils.clip_grad_norm_(ps, 0.5)
+    n, c = O.clip_coef(gs, 0.5)
+    assert abs(n - float(tot)) < 1e-5
+    for p, g in zip(ps, gs.values()):
+        assert torch.allclose(p.grad, g * c, rtol=1e-5, atol=1e-7)
+
+
+def test_dpo_tokenize_row():
+    r = O.dpo_tokenize_row([5, 6, 7, 8], [9, 10, 11], [12, 13], max_prompt_length=3, max_completion_length=3)
+    assert r == {"prompt_input_ids": [6, 7, 8], "chosen_input_ids": [9, 10, 11], "rejected_input_ids": [12, 13, 1]}
