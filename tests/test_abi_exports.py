@@ -1,0 +1,42 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol
+include/slam_engine.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+
+from slamkit_amd import engine as E
+
+
+def test_library_exports_every_declared_symbol():
+    lib = E.load_library()
+    names = E.header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/slam_engine.h but not exported"
+    # and the binding covers exactly the declared functions
+    assert sorted(lib._slam_signatures) == names
+
+
+def test_engine_layout_without_gpu():
+    lib = E.load_library()
+    assert b"gfx950" in lib.slam_version()
+    d = E.SlamModelDesc(24, 896, 14, 2, 64, 4864, 502, 0, 1e-6, 10000.0)
+    eng = E.Engine(d)
+    # 358,347,904 reference parameters + 10 zero pad rows of the 512-row embedding image
+    assert eng.n_params == 358_347_904 + 10 * 896
+    t = eng.tensors
+    assert t["embed"].rows == 512 and t["embed"].offset == 0
+    assert t["layers.0.wqkv"].rows == 1152 and t["layers.0.wgu"].rows == 9728
+    assert all(s.offset % 8 == 0 for s in t.values())
+    assert eng.workspace_bytes(8192) > 7 * 2**30
+    # bad descriptions are rejected with an error code, not a crash
+    h = C.c_void_p()
+    bad = E.SlamModelDesc(2, 100, 4, 2, 32, 512, 502, 0, 1e-6, 10000.0)
+    assert lib.slam_engine_create(C.byref(bad), C.byref(h)) == -1
+    assert lib.slam_backward(None, 1.0, 0, E.BUCKET_CB(0), None, None) == -1
+    eng.close()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+    with pytest.raises(OSError):
+        E.load_library(str(tmp_path / "nope.so"))

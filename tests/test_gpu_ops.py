@@ -1,0 +1,235 @@
+"""-m gpu parity tests, one HIP kernel at a time, each called through the C ABI and checked
+against a plain fp32 PyTorch reference of the same op on the same (bf16-representable) inputs.
+Tolerances: outputs are rounded to bf16 once (rel 2^-9 ~ 2e-3 rms); accumulations are fp32."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import check, dev_bf16, lib, ptr, rnd, stream, sync
+from oracle import slam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("glds", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 256, 128), (1000, 1152, 896),
+                                   (74, 512, 256)])
+def test_gemm_nt(M, N, K, glds):
+    X, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)  # keep alive: ptr() borrows
+    for use_bias, use_res in [(False, False), (True, True)]:
+        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd) if use_bias else None,
+                                   ptr(rd) if use_res else None, M, N, K, glds, stream())
+        sync()
+        assert rc == 0
+        ref = X @ W.t() + (bias if use_bias else 0) + (res if use_res else 0)
+        check(f"gemm_nt {M}x{N}x{K} glds={glds} epi={use_bias}", Y.float(), ref, 4e-3, 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 192, 384), (300, 512, 256), (1000, 1152, 896),
+                                   (74, 1024, 256)])
+def test_gemm_nn(M, N, K):
+    dY, W, res = rnd(M, N, seed=5), rnd(N, K, seed=6, scale=0.05), rnd(M, K, seed=7)
+    dYd, Wd, rd = dev_bf16(dY), dev_bf16(W), dev_bf16(res)
+    for use_res in (False, True):
+        dX = torch.full((M, K), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = lib().slam_op_gemm_nn(ptr(dYd), ptr(Wd), ptr(dX), ptr(rd) if use_res else None, M, N, K, stream())
+        sync()
+        assert rc == 0
+        check(f"gemm_nn {M}x{N}x{K} res={use_res}", dX.float(), dY @ W + (res if use_res else 0), 4e-3, 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (256, 128, 256), (300, 384, 128), (2048, 1152, 896),
+                                   (74, 512, 256), (1111, 128, 128)])
+def test_gemm_tn(M, N, K):
+    dY, X = rnd(M, N, seed=8), rnd(M, K, seed=9)
+    ws = torch.empty(lib().slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device="cuda")
+    dW = torch.full((N, K), 1.0, dtype=torch.float32, device="cuda")
+    a, b = dev_bf16(dY), dev_bf16(X)
+    assert lib().slam_op_gemm_tn(ptr(a), ptr(b), ptr(dW), 0, M, N, K, ptr(ws), stream()) == 0
+    sync()
+    ref = dY.t() @ X
+    check(f"gemm_tn {M}x{N}x{K}", dW, ref, 1e-5, 1e-4)
+    assert lib().slam_op_gemm_tn(ptr(a), ptr(b), ptr(dW), 1, M, N, K, ptr(ws), stream()) == 0
+    sync()
+    check(f"gemm_tn accumulate {M}x{N}x{K}", dW, 2 * ref, 1e-5, 1e-4)
+
+
+# --------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536)])
+def test_rmsnorm_fwd_bwd(M, H):
+    x, w, dy, dres = rnd(M, H, seed=1), 1 + 0.1 * rnd(H, seed=2), rnd(M, H, seed=3), rnd(M, H, seed=4)
+    w = w.to(torch.bfloat16).float()
+    xd, wd = dev_bf16(x), dev_bf16(w)
+    y = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    rstd = torch.empty(M, dtype=torch.float32, device="cuda")
+    assert lib().slam_op_rmsnorm_fwd(ptr(xd), ptr(wd), ptr(y), ptr(rstd), M, H, 1e-6, stream()) == 0
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = O.rms_norm(xr, wr, 1e-6)
+    sync()
+    check("rmsnorm_fwd", y.float(), yr.detach(), 3e-3, 1e-2)
+    check("rmsnorm rstd", rstd, torch.rsqrt(x.pow(2).mean(-1) + 1e-6), 1e-6)
+    yr.backward(dy)
+    ws = torch.empty(lib().slam_op_rmsnorm_bwd_workspace(M, H) // 4 + 16, dtype=torch.float32, device="cuda")
+    dx = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    dw = torch.full((H,), 7.0, dtype=torch.float32, device="cuda")
+    dyd, dresd = dev_bf16(dy), dev_bf16(dres)
+    for use_res in (False, True):
+        assert lib().slam_op_rmsnorm_bwd(ptr(dyd), ptr(xd), ptr(wd), ptr(rstd), ptr(dresd) if use_res else None,
+                                         ptr(dx), ptr(dw), ptr(ws), M, H, stream()) == 0
+        sync()
+        check(f"rmsnorm_bwd dx res={use_res}", dx.float(), xr.grad + (dres if use_res else 0), 3e-3, 1e-2)
+        check("rmsnorm_bwd dw", dw, wr.grad, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ RoPE
+@pytest.mark.parametrize("packed", [False, True])
+def test_rope(packed):
+    B, T, nH, nKV = 2, 75, 4, 2
+    M, ld = B * T, (nH + 2 * nKV) * 64
+    qkv = rnd(M, ld, seed=1)
+    if packed:
+        pos = torch.cat([torch.arange(40), torch.arange(60), torch.arange(50)])[None]
+    else:
+        pos = torch.arange(T)[None].expand(B, T)
+    buf = dev_bf16(qkv)
+    cs = torch.empty(2 * M * 32, dtype=torch.float32, device="cuda")
+    posd = pos.reshape(-1).contiguous().cuda() if packed else None
+    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, ptr(posd), 10000.0, 0, ptr(cs), stream()) == 0
+    sync()
+    q = qkv[:, : nH * 64].view(1, M, nH, 64).transpose(1, 2)
+    k = qkv[:, nH * 64: (nH + nKV) * 64].view(1, M, nKV, 64).transpose(1, 2)
+    cos, sin = O.rope_cos_sin(pos.reshape(1, M), 64, 10000.0)
+    qr, kr = O.apply_rope(q, k, cos, sin)
+    ref = qkv.clone()
+    ref[:, : nH * 64] = qr.transpose(1, 2).reshape(M, nH * 64)
+    ref[:, nH * 64: (nH + nKV) * 64] = kr.transpose(1, 2).reshape(M, nKV * 64)
+    check("rope fwd", buf.float(), ref, 3e-3, 1e-2)
+    # backward = transpose rotation: applying it to the forward result returns the input
+    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, ptr(posd), 10000.0, 1, ptr(cs), stream()) == 0
+    sync()
+    check("rope bwd(fwd(x)) == x", buf.float(), qkv, 6e-3, 3e-2)
+
+
+# ---------------------------------------------------------------------------------------- SwiGLU
+def test_swiglu():
+    M, I = 130, 512
+    gu, dact = rnd(M, 2 * I, seed=1, scale=2.0), rnd(M, I, seed=2)
+    gud = dev_bf16(gu)
+    act = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
+    assert lib().slam_op_swiglu_fwd(ptr(gud), ptr(act), M, I, stream()) == 0
+    g = gu[:, :I].clone().requires_grad_(True)
+    u = gu[:, I:].clone().requires_grad_(True)
+    ref = F.silu(g) * u
+    ref.backward(dact)
+    sync()
+    check("swiglu fwd", act.float(), ref.detach(), 3e-3, 1e-2)
+    dactd = dev_bf16(dact)
+    assert lib().slam_op_swiglu_bwd(ptr(gud), ptr(dactd), M, I, stream()) == 0
+    sync()
+    check("swiglu bwd", gud.float(), torch.cat([g.grad, u.grad], 1), 3e-3, 1e-2)
+
+
+# ------------------------------------------------------------------------------------- attention
+def _attn_case(seg_lens, nH, nKV, seed=0, spike=False):
+    M = sum(seg_lens)
+    ld = (nH + 2 * nKV) * 64
+    qkv = rnd(M, ld, seed=seed)
+    if spike:  # force big running-max jumps in the online softmax
+        qkv[5, :64] *= 8.0   # powers of two keep the values bf16-representable
+        qkv[3, nH * 64: nH * 64 + 64] *= 8.0
+    starts = []
+    s = 0
+    for n in seg_lens:
+        starts += [s] * n
+        s += n
+    seg_s = torch.tensor(starts, dtype=torch.int32)
+    ends = []
+    s = 0
+    for n in seg_lens:
+        ends += [s + n] * n
+        s += n
+    seg_e = torch.tensor(ends, dtype=torch.int32)
+    return M, ld, qkv, seg_s, seg_e
+
+
+def _attn_ref(qkv, seg_s, nH, nKV, d_o=None):
+    M = qkv.shape[0]
+    x = qkv.clone().requires_grad_(True)
+    q = x[:, : nH * 64].view(1, M, nH, 64).transpose(1, 2)
+    k = x[:, nH * 64: (nH + nKV) * 64].view(1, M, nKV, 64).transpose(1, 2)
+    v = x[:, (nH + nKV) * 64:].view(1, M, nKV, 64).transpose(1, 2)
+    i = torch.arange(M)
+    mask = ((i[None, :] <= i[:, None]) & (i[None, :] >= seg_s.long()[:, None]))[None]
+    o = O.attention(q, k, v, mask, 0.125).reshape(M, nH * 64)
+    if d_o is None:
+        return o.detach(), None
+    o.backward(d_o)
+    return o.detach(), x.grad
+
+
+@pytest.mark.parametrize("seg_lens,nH,nKV,spike", [
+    ([64], 2, 1, False), ([128], 2, 2, False), ([200], 4, 2, True), ([256, 256], 14, 2, False),
+    ([37, 100, 5, 130, 64], 4, 2, False), ([1024], 7, 1, False), ([29, 41, 17], 4, 2, True)])
+def test_attention_fwd_bwd(seg_lens, nH, nKV, spike):
+    M, ld, qkv, seg_s, seg_e = _attn_case(seg_lens, nH, nKV, seed=len(seg_lens), spike=spike)
+    d_o = rnd(M, nH * 64, seed=9)
+    o_ref, dqkv_ref = _attn_ref(qkv, seg_s, nH, nKV, d_o)
+    qd = dev_bf16(qkv)
+    o = torch.full((M, nH * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(nH * M, dtype=torch.float32, device="cuda")
+    ss, se = seg_s.cuda(), seg_e.cuda()
+    assert lib().slam_op_attn_fwd(ptr(qd), ptr(o), ptr(lse), ptr(ss), M, nH, nKV, stream()) == 0
+    sync()
+    check(f"attn fwd {seg_lens} nH={nH}", o.float(), o_ref, 6e-3, 3e-2)
+    # lse check (log2 domain) against the scaled scores
+    q = qkv[:, : nH * 64].view(M, nH, 64).transpose(0, 1)
+    k = qkv[:, nH * 64: (nH + nKV) * 64].view(M, nKV, 64).transpose(0, 1).repeat_interleave(nH // nKV, 0)
+    s = (q @ k.transpose(1, 2)) * 0.125
+    i = torch.arange(M)
+    mask = (i[None, :] <= i[:, None]) & (i[None, :] >= seg_s.long()[:, None])
+    s = s.masked_fill(~mask[None], float("-inf"))
+    check("attn lse2", lse.view(nH, M).cpu(), torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4)
+    # backward uses the bf16 O the forward produced (as the engine does)
+    ws = torch.empty(lib().slam_op_attn_bwd_workspace(M, nH) // 4 + 16, dtype=torch.float32, device="cuda")
+    dqkv = torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dod = dev_bf16(d_o)
+    assert lib().slam_op_attn_bwd(ptr(qd), ptr(o), ptr(dod), ptr(lse), ptr(dqkv), ptr(ws), ptr(ss), ptr(se),
+                                  M, nH, nKV, stream()) == 0
+    sync()
+    got = dqkv.float().cpu()
+    check("attn bwd dq", got[:, : nH * 64], dqkv_ref[:, : nH * 64], 1.5e-2, 6e-2)
+    check("attn bwd dk", got[:, nH * 64: (nH + nKV) * 64], dqkv_ref[:, nH * 64: (nH + nKV) * 64], 1.5e-2, 6e-2)
+    check("attn bwd dv", got[:, (nH + nKV) * 64:], dqkv_ref[:, (nH + nKV) * 64:], 1.5e-2, 6e-2)
+
+
+# --------------------------------------------------------------------------------- cross entropy
+@pytest.mark.parametrize("num_items", [0.0, 57.0])
+def test_cross_entropy(num_items):
+    B, T, V = 3, 41, 502
+    M = B * T
+    logits = rnd(M, 512, seed=1, scale=3.0)
+    labels = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(2))
+    labels[0, 5:9] = -100
+    labels[2, 30:] = -100
+    lg = dev_bf16(logits)
+    dl = torch.full((M, 512), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rl = torch.empty(M, dtype=torch.float32, device="cuda")
+    sc = torch.zeros(2, dtype=torch.float32, device="cuda")
+    labd = labels.cuda()
+    assert lib().slam_op_cross_entropy(ptr(lg), ptr(labd), num_items, ptr(dl), ptr(rl), ptr(sc), B, T, V,
+                                       stream()) == 0
+    sync()
+    x = logits[:, :V].view(B, T, V).clone().requires_grad_(True)
+    loss = O.compute_loss(x, labels, num_items_in_batch=(num_items if num_items > 0 else None))
+    loss.backward()
+    assert abs(float(sc[1]) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
+    got = dl.float().cpu().view(B, T, 512)
+    check("ce dlogits", got[:, :, :V], x.grad, 5e-3, 2e-2)
+    assert float(got[:, :, V:].abs().max()) == 0.0
