@@ -1,0 +1,398 @@
+"""Engine-backed UnitLM: the plugin surface of /root/reference slamkit/model/unit_lm.py
+(UnitLMConfig :32-79, UnitLM :82-212, compute_loss :13-29) with the HuggingFace Qwen2 forward /
+autograd backward replaced by the gfx950 HIP engine (include/slam_engine.h).
+
+Same call shapes: `model(input_ids, attention_mask, position_ids, labels, num_items_in_batch=...)`
+returns an object with `.loss` (fp32 scalar, `.backward()` works) and `.logits [B,T,V]` (bf16);
+`log_likelihood`, `generate`, `save_pretrained / from_pretrained` (HF state-dict key layout
+`lm.model.layers.{i}.self_attn.q_proj.weight` ..., SURVEY.md §5 checkpoint row) and
+`get_input_embeddings / get_output_embeddings` exist. There is no eager fallback: without the
+HIP library or a GPU, construction fails.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import torch
+
+from .. import engine as E
+from .token_lm import TokenLM
+
+# Qwen2.5-0.5B body (config/model/slam.yaml:7 base_model_name) - the hub is unreachable from a
+# training box, so the dims the reference pulls via AutoConfig.from_pretrained (unit_lm.py:64)
+# are carried here.
+KNOWN_BASE_CONFIGS = {
+    "Qwen/Qwen2.5-0.5B": dict(num_hidden_layers=24, hidden_size=896, num_attention_heads=14, num_key_value_heads=2,
+                              head_dim=64, intermediate_size=4864, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                              tie_word_embeddings=True, initializer_range=0.02),
+}
+
+
+@dataclass
+class UnitLMConfig:
+    """unit_lm.py:32-79. `base_config` is a dict of Qwen2Config-named fields (or None to look
+    `base_model_name` up in KNOWN_BASE_CONFIGS); extra kwargs such as `rope_theta` override it the
+    way the reference forwards **kwargs into AutoConfig.from_pretrained (config/model/slam.yaml:8)."""
+    base_model_name: str = "Qwen/Qwen2.5-0.5B"
+    base_config: Optional[dict] = None
+    vocab_size: int = 502
+    twist_init: bool = False
+    use_cache: bool = False
+    pad_token_id: int = 0
+    bos_token_id: int = 1
+    eos_token_id: int = 1
+    torch_dtype: Optional[str] = "bfloat16"
+    attn_implementation: Optional[str] = "flash_attention_2"  # the engine's attention is varlen-capable
+    max_tokens: int = 8192          # engine workspace capacity (B*T per micro-batch)
+    extra: dict = field(default_factory=dict)
+
+    def __init__(self, base_model_name="Qwen/Qwen2.5-0.5B", base_config=None, vocab_size=502, twist_init=False,
+                 use_cache=False, pad_token_id=0, bos_token_id=1, eos_token_id=1, torch_dtype="bfloat16",
+                 attn_implementation="flash_attention_2", max_tokens=8192, **kwargs):
+        self.base_model_name = base_model_name
+        if base_config is None:
+            if base_model_name not in KNOWN_BASE_CONFIGS:
+                raise ValueError(f"unknown base model {base_model_name!r}: pass base_config=dict(...) "
+                                 f"(no hub access); known: {sorted(KNOWN_BASE_CONFIGS)}")
+            base_config = dict(KNOWN_BASE_CONFIGS[base_model_name])
+        base_config = dict(base_config)
+        for k in list(kwargs):
+            if k in ("rope_theta", "rms_norm_eps", "initializer_range"):
+                base_config[k] = kwargs.pop(k)
+        base_config.setdefault("head_dim", base_config["hidden_size"] // base_config["num_attention_heads"])
+        base_config.setdefault("rms_norm_eps", 1e-6)
+        base_config.setdefault("rope_theta", 10000.0)
+        base_config.setdefault("initializer_range", 0.02)
+        base_config.setdefault("tie_word_embeddings", True)
+        base_config.update(pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id)
+        if not base_config["tie_word_embeddings"]:
+            raise ValueError("the engine supports tied embeddings only (Slam / Qwen2.5-0.5B)")
+        self.base_config = base_config
+        self.vocab_size = vocab_size
+        self.twist_init = twist_init
+        if twist_init:
+            raise ValueError("twist_init needs hub weights; load a converted checkpoint with from_pretrained instead")
+        self.use_cache = use_cache
+        self.pad_token_id, self.bos_token_id, self.eos_token_id = pad_token_id, bos_token_id, eos_token_id
+        self.torch_dtype = torch_dtype
+        self.attn_implementation = attn_implementation
+        self._attn_implementation = attn_implementation  # read at cli/train.py:43
+        self.max_tokens = max_tokens
+        self.tie_word_embeddings = True
+        self.extra = kwargs
+
+    def to_dict(self):
+        return dict(model_type="speech_language_model", engine="slamkit_amd", base_model_name=self.base_model_name,
+                    base_config=self.base_config, vocab_size=self.vocab_size, pad_token_id=self.pad_token_id,
+                    bos_token_id=self.bos_token_id, eos_token_id=self.eos_token_id, torch_dtype=self.torch_dtype,
+                    max_tokens=self.max_tokens)
+
+    def engine_desc(self) -> E.SlamModelDesc:
+        b = self.base_config
+        return E.SlamModelDesc(b["num_hidden_layers"], b["hidden_size"], b["num_attention_heads"],
+                               b["num_key_value_heads"], b["head_dim"], b["intermediate_size"], self.vocab_size,
+                               self.pad_token_id if self.pad_token_id is not None else -1,
+                               float(b["rms_norm_eps"]), float(b["rope_theta"]))
+
+
+@dataclass
+class CausalLMOutput:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class _EngineLoss(torch.autograd.Function):
+    """Lets `out.loss.backward()` drive slam_backward (plugin-surface compatibility). The trainer's
+    hot loop calls UnitLM.backward() directly and avoids the host read of grad_output."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model.backward(float(grad_out))
+        return torch.zeros(1, device=grad_out.device), None, None
+
+
+def _right_padded(mask: torch.Tensor) -> bool:
+    m = mask.to(torch.int64)
+    return bool((m[:, 1:] <= m[:, :-1]).all())
+
+
+class UnitLM(TokenLM):
+    """unit_lm.py:82-212 on the HIP engine."""
+    base_model_prefix = "lm"
+
+    def __init__(self, config: UnitLMConfig, device: Optional[str] = None, seed: int = 0, allocate_grads: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("slamkit_amd.UnitLM needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.engine = E.Engine(config.engine_desc())
+        n = self.engine.n_params
+        with torch.cuda.device(self.device):
+            self.flat_params = torch.zeros(n, dtype=torch.bfloat16, device=self.device)
+            self.flat_master = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device) if allocate_grads else None
+            self.engine.bind_params(self.flat_params, self.flat_grads)
+            self._ws = None
+            self._ws_tokens = 0
+            self._ensure_workspace(config.max_tokens)
+            self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self.training = True
+        self._build_key_map()
+        self.init_weights(seed)
+
+    # ---- layout ------------------------------------------------------------------------------
+    def _build_key_map(self):
+        b, t = self.config.base_config, self.engine.tensors
+        nH, nKV, hd, I = b["num_attention_heads"], b["num_key_value_heads"], b["head_dim"], b["intermediate_size"]
+        H = b["hidden_size"]
+        km: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        km["lm.model.embed_tokens.weight"] = (t["embed"].offset, (self.config.vocab_size, H))
+        for l in range(b["num_hidden_layers"]):
+            p, q = f"lm.model.layers.{l}.", f"layers.{l}."
+            o = t[q + "wqkv"].offset
+            km[p + "self_attn.q_proj.weight"] = (o, (nH * hd, H))
+            km[p + "self_attn.k_proj.weight"] = (o + nH * hd * H, (nKV * hd, H))
+            km[p + "self_attn.v_proj.weight"] = (o + (nH + nKV) * hd * H, (nKV * hd, H))
+            o = t[q + "bqkv"].offset
+            km[p + "self_attn.q_proj.bias"] = (o, (nH * hd,))
+            km[p + "self_attn.k_proj.bias"] = (o + nH * hd, (nKV * hd,))
+            km[p + "self_attn.v_proj.bias"] = (o + (nH + nKV) * hd, (nKV * hd,))
+            km[p + "self_attn.o_proj.weight"] = (t[q + "wo"].offset, (H, nH * hd))
+            o = t[q + "wgu"].offset
+            km[p + "mlp.gate_proj.weight"] = (o, (I, H))
+            km[p + "mlp.up_proj.weight"] = (o + I * H, (I, H))
+            km[p + "mlp.down_proj.weight"] = (t[q + "wd"].offset, (H, I))
+            km[p + "input_layernorm.weight"] = (t[q + "ln1"].offset, (H,))
+            km[p + "post_attention_layernorm.weight"] = (t[q + "ln2"].offset, (H,))
+        km["lm.model.norm.weight"] = (t["norm"].offset, (H,))
+        self.key_map = km
+
+    def _view(self, flat: torch.Tensor, key: str) -> torch.Tensor:
+        off, shp = self.key_map[key]
+        n = 1
+        for s in shp:
+            n *= s
+        return flat[off:off + n].view(*shp)
+
+    def _ensure_workspace(self, tokens: int):
+        if tokens <= self._ws_tokens:
+            return
+        nbytes = self.engine.workspace_bytes(tokens)
+        self._ws = None
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        self._ws_aligned = self._ws[off:off + nbytes]
+        self.engine.bind_workspace(self._ws_aligned, tokens)
+        self._ws_tokens = tokens
+
+    # ---- parameters ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def init_weights(self, seed: int = 0):
+        """HF `_init_weights`: N(0, initializer_range) matrices and embeddings, zero biases, unit
+        norms, zero padding_idx row (unit_lm.py:114-115 -> transformers PreTrainedModel)."""
+        std = float(self.config.base_config["initializer_range"])
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        self.flat_master.zero_()
+        for k in self.key_map:
+            v = self._view(self.flat_master, k)
+            if k.endswith("norm.weight"):
+                v.fill_(1.0)
+            elif k.endswith(".bias"):
+                v.zero_()
+            else:
+                v.normal_(0.0, std, generator=g)
+        if self.config.pad_token_id is not None and self.config.pad_token_id >= 0:
+            self._view(self.flat_master, "lm.model.embed_tokens.weight")[self.config.pad_token_id].zero_()
+        self.sync_params_from_master()
+
+    def sync_params_from_master(self):
+        self.engine.cast_params(self.flat_master)
+
+    def named_parameters(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        for k in self.key_map:
+            yield k, self._view(self.flat_params, k)
+
+    def parameters(self) -> Iterator[torch.Tensor]:
+        for _, v in self.named_parameters():
+            yield v
+
+    def named_grads(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        for k in self.key_map:
+            yield k, self._view(self.flat_grads, k)
+
+    def num_parameters(self) -> int:
+        return sum(v.numel() for v in self.parameters())
+
+    def state_dict(self, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+        src = self.flat_master if dtype == torch.float32 else self.flat_params
+        return {k: self._view(src, k).detach().to(dtype).cpu().clone() for k in self.key_map}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        missing = [k for k in self.key_map if k not in sd]
+        extra = [k for k in sd if k not in self.key_map and not k.endswith("lm_head.weight")]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing={missing[:4]} unexpected={extra[:4]}")
+        for k in self.key_map:
+            if k in sd:
+                v = self._view(self.flat_master, k)
+                src = sd[k]
+                if k == "lm.model.embed_tokens.weight" and src.shape[0] > v.shape[0]:
+                    src = src[: v.shape[0]]  # resize_token_embeddings keeps the first V rows (unit_lm.py:102)
+                v.copy_(src.to(device=self.device, dtype=torch.float32))
+        self.sync_params_from_master()
+        return missing, extra
+
+    def get_input_embeddings(self):
+        return self._view(self.flat_params, "lm.model.embed_tokens.weight")
+
+    def get_output_embeddings(self):
+        return self.get_input_embeddings()  # tied
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- forward / backward ---------------------------------------------------------------------
+    def _segments(self, position_ids: torch.Tensor):
+        """Packed [1, sum T] batches (DataCollatorWithFlattening): per-token sequence bounds from
+        position_ids == 0 restarts."""
+        pos = position_ids.reshape(-1)
+        M = pos.numel()
+        idx = torch.arange(M, device=pos.device, dtype=torch.int64)
+        is0 = pos == 0
+        start = torch.cummax(torch.where(is0, idx, torch.zeros_like(idx)), 0).values
+        nxt = torch.where(is0, idx, torch.full_like(idx, M))
+        # end = position of the next restart strictly after the token
+        nxt_shift = torch.cat([nxt[1:], torch.full((1,), M, device=pos.device, dtype=torch.int64)])
+        end = torch.flip(torch.cummin(torch.flip(nxt_shift, [0]), 0).values, [0])
+        return start.to(torch.int32).contiguous(), end.to(torch.int32).contiguous()
+
+    def forward(self, input_ids: torch.Tensor = None, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                num_items_in_batch=None, return_logits: bool = True, **unused) -> CausalLMOutput:
+        """UnitLM.forward (unit_lm.py:135-182). `attention_mask` must be right padding (what
+        DataCollatorForLanguageModeling produces): under the causal mask it never changes a real
+        token's output, so the engine does not read it."""
+        assert input_ids is not None and input_ids.dim() == 2
+        B, T = input_ids.shape
+        if attention_mask is not None and not attention_mask.is_cuda and not _right_padded(attention_mask):
+            raise ValueError("only right-padded attention_mask is supported")
+        dev = self.device
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        lab = labels.to(dev, torch.int64).contiguous() if labels is not None else None
+        self._ensure_workspace(B * T)
+        seg_s = seg_e = pos = None
+        if position_ids is not None:
+            pos = position_ids.to(dev, torch.int64).contiguous()
+            if B == 1:
+                seg_s, seg_e = self._segments(pos)
+        logits = torch.empty(B, T, self.config.vocab_size, dtype=torch.bfloat16, device=dev) if return_logits else None
+        if isinstance(num_items_in_batch, torch.Tensor):
+            num_items_in_batch = float(num_items_in_batch)
+        self._hold = (ids, lab, pos, seg_s, seg_e)  # the engine borrows these until backward
+        self.engine.forward(ids, lab, pos, seg_s, seg_e, B, T,
+                            float(num_items_in_batch) if num_items_in_batch else 0.0,
+                            self._loss_buf if lab is not None else None, logits)
+        loss = None
+        if lab is not None:
+            loss = _EngineLoss.apply(self._anchor, self, self._loss_buf) if torch.is_grad_enabled() else self._loss_buf.clone()
+        return CausalLMOutput(loss=loss, logits=logits)
+
+    __call__ = forward
+
+    def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0, bucket_cb=None):
+        """d(loss * grad_scale)/dparams accumulated into `flat_grads` (fp32)."""
+        self.engine.backward(grad_scale, bucket_layers, bucket_cb)
+
+    def zero_grad(self):
+        self.engine.zero_grads()
+
+    @torch.no_grad()
+    def log_likelihood(self, tokens: torch.Tensor, mean_nll: bool, ignore_tokens: Optional[List[int]] = None) -> torch.Tensor:
+        """unit_lm.py:184-194 + calc_nll (calculation_utils.py:5-29): pad -> -100, per-sequence
+        sum (or mean) of target log-probs."""
+        if ignore_tokens is not None:
+            raise NotImplementedError("ignore_tokens masking is an interleaved-tokeniser feature (out of scope)")
+        B, T = tokens.shape
+        ids = tokens.to(self.device, torch.int64).contiguous()
+        lab = ids.clone()
+        lab[lab == self.config.pad_token_id] = -100
+        self._ensure_workspace(B * T)
+        self._hold = (ids, lab)
+        self.engine.forward(ids, lab, None, None, None, B, T, 0.0, self._loss_buf, None)
+        ll = torch.empty(B, dtype=torch.float32, device=self.device)
+        cnt = torch.empty(B, dtype=torch.float32, device=self.device)
+        self.engine.seq_loglik(lab, B, T, ll, cnt)
+        return ll / cnt if mean_nll else ll
+
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, generation_config=None, max_new_tokens: int = 32,
+                 do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, seed: Optional[int] = None,
+                 **kwargs) -> torch.Tensor:
+        """Minimal sampler for the TokenLM surface (unit_lm.py:196-198): full re-forward per token
+        (no KV cache - evaluation/generation is outside the training hot path)."""
+        if generation_config is not None:
+            max_new_tokens = getattr(generation_config, "max_new_tokens", max_new_tokens) or max_new_tokens
+            do_sample = getattr(generation_config, "do_sample", do_sample)
+        seq = inputs.to(self.device, torch.int64)
+        g = torch.Generator(device=self.device)
+        if seed is not None:
+            g.manual_seed(seed)
+        done = torch.zeros(seq.shape[0], dtype=torch.bool, device=self.device)
+        for _ in range(max_new_tokens):
+            logits = self.forward(seq).logits[:, -1].float()
+            if do_sample:
+                logits = logits / max(temperature, 1e-6)
+                if top_k:
+                    kth = torch.topk(logits, top_k).values[:, -1:]
+                    logits = logits.masked_fill(logits < kth, float("-inf"))
+                nxt = torch.multinomial(torch.softmax(logits, -1), 1, generator=g)[:, 0]
+            else:
+                nxt = logits.argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, self.config.pad_token_id), nxt)
+            seq = torch.cat([seq, nxt[:, None]], 1)
+            done |= nxt == self.config.eos_token_id
+            if bool(done.all()):
+                break
+        return seq
+
+    # ---- checkpoints (HF layout) ------------------------------------------------------------------
+    def save_pretrained(self, save_directory: str, dtype=torch.bfloat16):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        sd = self.state_dict(dtype)
+        save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f, indent=1)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, **kwargs) -> "UnitLM":
+        from safetensors.torch import load_file
+        with open(os.path.join(pretrained_model_name_or_path, "config.json")) as f:
+            c = json.load(f)
+        cfg = UnitLMConfig(base_model_name=c.get("base_model_name", "local"), base_config=c["base_config"],
+                           vocab_size=c["vocab_size"], pad_token_id=c.get("pad_token_id", 0),
+                           bos_token_id=c.get("bos_token_id", 1), eos_token_id=c.get("eos_token_id", 1),
+                           max_tokens=kwargs.pop("max_tokens", c.get("max_tokens", 8192)))
+        m = cls(cfg, **kwargs)
+        m.load_state_dict(load_file(os.path.join(pretrained_model_name_or_path, "model.safetensors")), strict=False)
+        return m

@@ -1,0 +1,275 @@
+"""SLAMTrainer on the HIP engine: the step loop transformers.Trainer runs for the reference
+(/root/reference slamkit/trainer/slam_trainer.py:27-71 over site-packages transformers/trainer.py
+_inner_training_loop) restated around UnitLM.forward/backward,
+slam_grad_norm + slam_adamw_step and the bucketed RCCL reducer.
+
+Differences from the reference that are deliberate (and loss-equivalent):
+ * tokens-seen and num_items_in_batch are counted on the host from the collated CPU labels and
+   all-reduced ONCE per optimizer step, instead of a device->host sync + all-gather on every
+   micro-step (slam_trainer.py:70);
+ * the loss is read back only every `logging_steps`;
+ * gradients are all-reduced as a few large ranges of one flat fp32 buffer, overlapped with the
+   backward of the last micro-batch (no_sync on the others, like trainer.py:1750-1758).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import shutil
+import time
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .callbacks import TrainerCallback, TrainerControl, TrainerState
+from .dp import GradBucketReducer, all_reduce_scalar, seeded_batches, shard_batches, world_info
+from .training_args import SLAMTrainingArguments, lr_lambda
+
+logger = logging.getLogger(__name__)
+
+
+class SLAMTrainer:
+    def __init__(self, model=None, args: SLAMTrainingArguments = None, data_collator: Callable = None,
+                 train_dataset=None, eval_dataset=None, processing_class=None, callbacks: Optional[List[TrainerCallback]] = None):
+        self.model = model
+        self.args = args or SLAMTrainingArguments()
+        self.data_collator = data_collator
+        self.train_dataset = train_dataset
+        self.eval_dataset = eval_dataset
+        self.processing_class = processing_class
+        self.callbacks = list(callbacks or [])
+        self.state = TrainerState()
+        self.control = TrainerControl()
+        self.rank, self.world = world_info()
+        dev = model.device
+        n = model.engine.n_params
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.reducer = GradBucketReducer(model.flat_grads)
+        self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._loss_n = 0
+        self.opt_step = 0
+
+    # ---- reference hooks ------------------------------------------------------------------------
+    def get_num_tokens(self, labels: torch.Tensor) -> int:
+        """slam_trainer.py:59-65 (host-side count on the collated labels)."""
+        valid = labels != -100
+        if self.args.min_token_id_count is not None:
+            valid = torch.logical_and(valid, labels >= self.args.min_token_id_count)
+        if self.args.max_token_id_count is not None:
+            valid = torch.logical_and(valid, labels <= self.args.max_token_id_count)
+        return int(valid.sum())
+
+    def training_step(self, model, inputs: Dict[str, torch.Tensor], num_items_in_batch=None, last_micro: bool = True,
+                      grad_scale: float = 1.0) -> torch.Tensor:
+        """slam_trainer.py:67-71 + Trainer.training_step: forward + backward of one micro-batch.
+        Returns the (device) loss tensor without synchronising."""
+        out = model.forward(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"),
+                            position_ids=inputs.get("position_ids"), labels=inputs["labels"],
+                            num_items_in_batch=num_items_in_batch, return_logits=False)
+        loss = out.loss.detach()
+        if last_micro and self.world > 1:
+            model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
+        else:
+            model.backward(grad_scale)
+        return loss
+
+    # ---- schedule -----------------------------------------------------------------------------------
+    def _plan(self):
+        a = self.args
+        n = len(self.train_dataset)
+        per_epoch_batches = math.ceil(n / a.per_device_train_batch_size)
+        per_rank = math.ceil(per_epoch_batches / self.world)
+        updates_per_epoch = max(1, math.ceil(per_rank / a.gradient_accumulation_steps))
+        if a.max_steps and a.max_steps > 0:
+            max_steps = a.max_steps
+            epochs = math.ceil(max_steps / updates_per_epoch)
+        else:
+            max_steps = math.ceil(a.num_train_epochs * updates_per_epoch)
+            epochs = math.ceil(a.num_train_epochs)
+        return max_steps, epochs, updates_per_epoch
+
+    def _epoch_batches(self, epoch: int):
+        a = self.args
+        batches = seeded_batches(len(self.train_dataset), a.per_device_train_batch_size, a.seed, epoch)
+        return shard_batches(batches, self.rank, self.world, even=True)
+
+    def _collate(self, idxs):
+        return self.data_collator([self.train_dataset[i] for i in idxs])
+
+    # ---- one optimizer step over `micro` collated CPU micro-batches -------------------------------------
+    def optimizer_step(self, micro: List[Dict[str, torch.Tensor]], lr: float):
+        a = self.args
+        local_items = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
+        if a.min_token_id_count is None and a.max_token_id_count is None:
+            local_seen = local_items
+        else:
+            local_seen = float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
+        if self.world > 1:
+            t = torch.tensor([local_items, local_seen], dtype=torch.float64, device=self.model.device)
+            dist.all_reduce(t)
+            glob_items, glob_seen = (float(x) for x in t.tolist())
+        else:
+            glob_items, glob_seen = local_items, local_seen
+        if a.average_tokens_across_devices:
+            n_items, scale = glob_items, 1.0           # sum over ranks of d(local_sum / global_count)
+        else:
+            n_items, scale = local_items, 1.0 / self.world  # per-rank token mean, then rank average
+        for i, mb in enumerate(micro):
+            loss = self.training_step(self.model, mb, num_items_in_batch=n_items, last_micro=(i == len(micro) - 1),
+                                      grad_scale=scale)
+            self._loss_acc += loss if a.average_tokens_across_devices else loss / len(micro)
+        self._loss_n += 1
+        self.reducer.finish()
+        self.state.num_input_tokens_seen += int(glob_seen)
+        eng = self.model.engine
+        eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
+        self.opt_step += 1
+        eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
+                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=True)
+        self.state.global_step += 1
+
+    def _log(self, lr: float, t0: float, tokens0: int):
+        loss_local = float(self._loss_acc) / max(1, self._loss_n)
+        loss = all_reduce_scalar(loss_local, device=self.model.device) if self.world > 1 else loss_local
+        if not self.args.average_tokens_across_devices and self.world > 1:
+            loss /= self.world
+        self._loss_acc.zero_()
+        self._loss_n = 0
+        dt = time.time() - t0
+        rec = {"step": self.state.global_step, "loss": loss, "grad_norm": float(self.norm_out[0]), "learning_rate": lr,
+               "num_input_tokens_seen": self.state.num_input_tokens_seen,
+               "tokens_per_sec": (self.state.num_input_tokens_seen - tokens0) / max(dt, 1e-9)}
+        self.state.log_history.append(rec)
+        if self.rank == 0:
+            logger.info(json.dumps(rec))
+        return rec
+
+    # ---- train ------------------------------------------------------------------------------------------------
+    def train(self, resume_from_checkpoint=None):
+        a = self.args
+        max_steps, epochs, updates_per_epoch = self._plan()
+        self.state.max_steps = max_steps
+        if resume_from_checkpoint:
+            path = resume_from_checkpoint if isinstance(resume_from_checkpoint, str) else self._last_checkpoint()
+            if path:
+                self._load_checkpoint(path)
+        self.model.zero_grad()
+        for cb in self.callbacks:
+            cb.on_train_begin(a, self.state, self.control)
+        t0, tokens0 = time.time(), self.state.num_input_tokens_seen
+        start_epoch = self.state.global_step // updates_per_epoch
+        skip = (self.state.global_step % updates_per_epoch) * a.gradient_accumulation_steps
+        done = self.state.global_step >= max_steps
+        for epoch in range(start_epoch, max(epochs, start_epoch + 1)):
+            if done:
+                break
+            batches = self._epoch_batches(epoch)[skip:]
+            skip = 0
+            for s in range(0, len(batches), a.gradient_accumulation_steps):
+                micro = [self._collate(b) for b in batches[s:s + a.gradient_accumulation_steps]]
+                lr = a.learning_rate * lr_lambda(a, self.state.global_step, max_steps)
+                self.optimizer_step(micro, lr)
+                self.state.epoch = self.state.global_step / updates_per_epoch
+                for cb in self.callbacks:
+                    cb.on_step_end(a, self.state, self.control)
+                if self.world > 1 and self.callbacks:  # a wall-clock stop must be taken by every rank together
+                    flag = all_reduce_scalar(1.0 if self.control.should_training_stop else 0.0, device=self.model.device)
+                    self.control.should_training_stop = flag > 0
+                if a.logging_steps and self.state.global_step % a.logging_steps == 0:
+                    self._log(lr, t0, tokens0)
+                if (a.eval_strategy == "steps" and a.eval_steps and self.state.global_step % a.eval_steps == 0) \
+                        or self.control.should_evaluate:
+                    self.evaluate()
+                    self.control.should_evaluate = False
+                if (a.save_steps and self.state.global_step % a.save_steps == 0) or self.control.should_save:
+                    self.save_checkpoint()
+                    self.control.should_save = False
+                if self.state.global_step >= max_steps or self.control.should_training_stop:
+                    done = True
+                    break
+        if self._loss_n:
+            self._log(a.learning_rate * lr_lambda(a, max(self.state.global_step - 1, 0), max_steps), t0, tokens0)
+        for cb in self.callbacks:
+            cb.on_train_end(a, self.state, self.control)
+        torch.cuda.synchronize(self.model.device)
+        return self.state
+
+    @torch.no_grad()
+    def evaluate(self, dataset=None) -> Dict[str, float]:
+        ds = dataset if dataset is not None else self.eval_dataset
+        if ds is None or len(ds) == 0:
+            return {}
+        bs = self.args.per_device_eval_batch_size
+        idx = list(range(len(ds)))
+        batches = shard_batches([idx[i:i + bs] for i in range(0, len(idx), bs)], self.rank, self.world, even=False)
+        tot, cnt = torch.zeros(1, dtype=torch.float64, device=self.model.device), 0.0
+        for b in batches:
+            mb = self.data_collator([ds[i] for i in b])
+            n = float(((mb["labels"][:, 1:]) != -100).sum())
+            if n == 0:
+                continue
+            out = self.model.forward(input_ids=mb["input_ids"], position_ids=mb.get("position_ids"), labels=mb["labels"],
+                                     num_items_in_batch=1.0, return_logits=False)
+            tot += out.loss.double()
+            cnt += n
+        if self.world > 1:
+            t = torch.cat([tot, torch.tensor([cnt], dtype=torch.float64, device=self.model.device)])
+            dist.all_reduce(t)
+            tot, cnt = t[:1], float(t[1])
+        res = {"eval_loss": float(tot) / max(cnt, 1.0), "step": self.state.global_step}
+        self.state.log_history.append(res)
+        if self.rank == 0:
+            logger.info(json.dumps(res))
+        return res
+
+    # ---- checkpoints --------------------------------------------------------------------------------------------
+    def _ckpt_dir(self, step):
+        return os.path.join(self.args.output_dir, f"checkpoint-{step}")
+
+    def _last_checkpoint(self):
+        d = self.args.output_dir
+        if not os.path.isdir(d):
+            return None
+        c = [x for x in os.listdir(d) if x.startswith("checkpoint-") and x.split("-")[1].isdigit()]
+        return os.path.join(d, max(c, key=lambda x: int(x.split("-")[1]))) if c else None
+
+    def save_checkpoint(self):
+        """HF-layout weights (UnitLM.save_pretrained) + optimizer/trainer state; keeps save_total_limit."""
+        if self.rank == 0:
+            path = self._ckpt_dir(self.state.global_step)
+            self.model.save_pretrained(path)
+            torch.save({"master": self.model.flat_master.cpu(), "exp_avg": self.exp_avg.cpu(),
+                        "exp_avg_sq": self.exp_avg_sq.cpu(), "opt_step": self.opt_step}, os.path.join(path, "optimizer.pt"))
+            with open(os.path.join(path, "trainer_state.json"), "w") as f:
+                json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch,
+                           "num_input_tokens_seen": self.state.num_input_tokens_seen,
+                           "log_history": self.state.log_history}, f)
+            if self.processing_class is not None and hasattr(self.processing_class, "save_pretrained"):
+                self.processing_class.save_pretrained(path)
+            lim = self.args.save_total_limit
+            if lim:
+                c = sorted([x for x in os.listdir(self.args.output_dir) if x.startswith("checkpoint-")],
+                           key=lambda x: int(x.split("-")[1]))
+                for old in c[:-lim]:
+                    shutil.rmtree(os.path.join(self.args.output_dir, old), ignore_errors=True)
+        if self.world > 1:
+            dist.barrier()
+
+    def _load_checkpoint(self, path: str):
+        st = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+        self.model.flat_master.copy_(st["master"])
+        self.model.sync_params_from_master()
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.opt_step = int(st["opt_step"])
+        with open(os.path.join(path, "trainer_state.json")) as f:
+            s = json.load(f)
+        self.state.global_step = s["global_step"]
+        self.state.epoch = s["epoch"]
+        self.state.num_input_tokens_seen = s["num_input_tokens_seen"]
+        self.state.log_history = s.get("log_history", [])
