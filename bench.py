@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py - train tokens/sec of the Slam-358M pre-training step on N MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one full optimizer step of configs[1] (Slam-358M, unit_hubert_25 vocab 502, ctx 1024, bf16,
+per-GPU micro-batch 8, GA 1): forward + shifted CE + backward + (N>1: bucketed RCCL gradient all-reduce
+overlapped with backward) + global-norm clip 0.5 + AdamW, on synthetic unit-token batches already
+resident in HBM. Weak scaling (per-GPU work fixed). Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline     - dominant kernel (the gate|up projection GEMM, M=8192 N=9728 K=896): algorithmic flops per
+                 launch / mean launch time measured here with HIP events on the launch stream, against the
+                 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md). `step_frac` is the whole-step
+                 figure: tokens/s x 2.282 GFLOP/token / peak.
+  cpu_baseline - the fp32 CPU oracle (oracle/slam_oracle.py, a port of the reference step: it cannot run the
+                 reference's cli/train.py itself) timed on this box's host cores on a bounded
+                 sample (B=1, T=1024 fwd+bwd+AdamW).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TOKEN = 2.282e9       # fwd+bwd, causal-exact, T=1024
+PEAK_BF16 = 2.5e15             # dense MFMA peak, MI355X_MICROARCH.md
+B, T, V = 8, 1024, 502
+
+
+def synth_batch(rank: int, i: int, device):
+    g = torch.Generator().manual_seed(1234 + rank + 1000 * i)
+    ids = torch.randint(2, V, (B, T), generator=g)
+    ids[:, 0] = 1
+    ids = ids.to(device)
+    return {"input_ids": ids, "labels": ids}
+
+
+def dominant_kernel_roofline(model, iters=20):
+    """gate|up projection forward GEMM of one layer at the bench shape, timed with HIP events on the
+    stream it is launched on (torch's current stream)."""
+    from slamkit_amd import engine as E
+    lib = E.load_library()
+    M, N, K = B * T, 2 * 4864, 896
+    x = (torch.randn(M, K, device=model.device) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=model.device) * 0.02).to(torch.bfloat16)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=model.device)
+    st = E.current_stream_ptr()
+    for _ in range(3):
+        lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 1, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 1, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * N * K
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<nt,glds> gate|up M8192 N9728 K896", "achieved": round(ach, 1),
+            "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
+            "ms_per_launch": round(ms, 4), "traffic": None}
+
+
+def cpu_baseline(steps=2):
+    """fp32 oracle step (fwd + shifted CE + bwd + AdamW) on the host cores, B=1 x T=1024."""
+    from oracle import slam_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.SLAM_358M
+    sd = O.init_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(2, V, (1, T), generator=g)
+    ids[:, 0] = 1
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(v) for k, v in sd.items()}
+    times = []
+    for s in range(steps + 1):
+        t0 = time.time()
+        _, _, grads = O.forward_loss_grads(cfg, sd, ids, ids)
+        _, coef = O.clip_coef(grads, 0.5)
+        for k in sd:
+            O.adamw_update(sd[k], grads[k] * coef, m[k], v[k], s + 1, 1e-3)
+        times.append(time.time() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round((T - 1) / dt, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 fwd+CE+bwd+clip+AdamW, Slam-358M, B=1 T=1024, median of {steps} steps after 1 warm-up",
+            "sec_per_step": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-accum", type=int, default=1)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from slamkit_amd.model import UnitLM, UnitLMConfig
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+
+    cfg = UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=V, max_tokens=B * T)
+    model = UnitLM(cfg, seed=0)
+    args = SLAMTrainingArguments(per_device_train_batch_size=B, gradient_accumulation_steps=a.grad_accum,
+                                 learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0)
+    trainer = SLAMTrainer(model=model, args=args)
+    nb = 4
+    batches = [[synth_batch(rank, i * a.grad_accum + j, dev) for j in range(a.grad_accum)] for i in range(nb)]
+    n_items = float(B * T * a.grad_accum)   # HF num_items_in_batch counts unshifted labels != -100
+    trained_tokens = B * T * a.grad_accum  # SLAMTrainer.get_num_tokens definition: labels != -100 (slam_trainer.py:59-65)
+
+    def step(i):
+        trainer.optimizer_step(batches[i % nb], 1e-3, counts=(n_items, n_items))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(trainer._loss_acc) / max(1, trainer._loss_n)
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * trained_tokens * a.steps / dt
+        out = {
+            "metric": "train tokens/sec (whole node), Slam-358M ctx=1024", "value": round(value, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: Slam-358M (Qwen2.5-0.5B body, vocab 502, rope_theta 1e4), ctx=1024, "
+                                   "synthetic unit-token stream, random-init weights; full optimizer step",
+                       "model": "Slam-358M", "global_batch": world * B * a.grad_accum, "micro_batch": B, "seq_len": T,
+                       "grad_accum": a.grad_accum, "parallelism": f"dp{world}",
+                       "optimizer": "AdamW fp32 master+moments, clip 0.5", "final_loss": round(loss, 4)},
+        }
+        roof = dominant_kernel_roofline(model)
+        roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)
+        roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
+        out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            del trainer, model
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,18 @@ def world_info():
     return 0, 1
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo group for host-side scalars (token counts, stop flags): keeps tiny collectives off the
+    GPU streams. All ranks must call this at the same point (SLAMTrainer.__init__)."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
 class GradBucketReducer:
     def __init__(self, flat_grads: torch.Tensor, group=None):
         self.flat = flat_grads

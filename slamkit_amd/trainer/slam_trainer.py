@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from .callbacks import TrainerCallback, TrainerControl, TrainerState
-from .dp import GradBucketReducer, all_reduce_scalar, seeded_batches, shard_batches, world_info
+from .dp import GradBucketReducer, all_reduce_scalar, host_group, seeded_batches, shard_batches, world_info
 from .training_args import SLAMTrainingArguments, lr_lambda
 
 logger = logging.getLogger(__name__)
@@ -50,6 +50,7 @@ class SLAMTrainer:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.reducer = GradBucketReducer(model.flat_grads)
+        self.host_group = host_group() if self.world > 1 else None
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
         self.opt_step = 0
@@ -102,16 +103,23 @@ class SLAMTrainer:
         return self.data_collator([self.train_dataset[i] for i in idxs])
 
     # ---- one optimizer step over `micro` collated CPU micro-batches -------------------------------------
-    def optimizer_step(self, micro: List[Dict[str, torch.Tensor]], lr: float):
+    def optimizer_step(self, micro: List[Dict[str, torch.Tensor]], lr: float, counts=None):
+        """`counts` = (local num_items, local tokens seen) when the caller already knows them (device-
+        resident synthetic batches); otherwise counted on the host from the CPU labels."""
         a = self.args
-        local_items = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
-        if a.min_token_id_count is None and a.max_token_id_count is None:
-            local_seen = local_items
+        if counts is not None:
+            local_items, local_seen = float(counts[0]), float(counts[1])
         else:
-            local_seen = float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
+            local_items = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
+            if a.min_token_id_count is None and a.max_token_id_count is None:
+                local_seen = local_items
+            else:
+                local_seen = float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
         if self.world > 1:
-            t = torch.tensor([local_items, local_seen], dtype=torch.float64, device=self.model.device)
-            dist.all_reduce(t)
+            # host-side (gloo) all-reduce: the counts come from CPU labels, and a device collective here
+            # would stall the host behind the previous step's kernels
+            t = torch.tensor([local_items, local_seen], dtype=torch.float64)
+            dist.all_reduce(t, group=self.host_group)
             glob_items, glob_seen = (float(x) for x in t.tolist())
         else:
             glob_items, glob_seen = local_items, local_seen
