@@ -73,6 +73,11 @@ int32_t slam_tensor_count(SlamEngine* h);
 int slam_tensor_info(SlamEngine* h, int32_t index, SlamTensorInfo* out);
 /* params: bf16 [slam_param_count], grads: fp32 [slam_param_count] (model.parameters() / .grad) */
 int slam_bind_params(SlamEngine* h, void* params_bf16, float* grads_f32);
+/* Optional bf16 [slam_param_count] buffer that receives every weight matrix TRANSPOSED (same
+ * offsets): with it the dgrad GEMMs dX = dY W run as the fast contraction-contiguous form
+ * dY (W^T)^T. Refreshed by slam_adamw_step / slam_cast_params / slam_refresh_transposed. */
+int slam_bind_params_t(SlamEngine* h, void* params_t_bf16);
+int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream);
 
 /* ---- workspace ------------------------------------------------------------------------------*/
 size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens);

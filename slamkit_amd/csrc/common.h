@@ -59,11 +59,15 @@ SLAM_DEVICE f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
 }
 
 // LDS operand-tile layout shared by GEMM and attention: rows of 64 bf16 (128 B), eight
-// 16-byte chunks per row, chunk index XOR-swizzled with (row>>1)&7 so that the 16-lane groups
-// of a ds_read_b128 fragment read (16 consecutive rows, same chunk) hit 16 distinct slots.
-SLAM_DEVICE int lds_tile_off(int row, int chunk) {
-  return row * 128 + (((chunk) ^ ((row >> 1) & 7)) << 4);
-}
+// 16-byte chunks per row, chunk index XOR-swizzled with key(row) = ((row>>1) ^ (row>>4)) & 7:
+//  * fragment reads (ds_read_b128: 16 consecutive rows of a 16-aligned group, same chunk) see
+//    (row>>1)&7 xor a group constant -> 16 distinct slots of the 256-byte bank row, conflict-free;
+//  * direct / LDS-DMA staging writes one row's 8 chunks per 8-lane group -> conflict-free;
+//  * transposed staging writes rows 8j + rr (j = 8 consecutive lanes) of one chunk per
+//    ds_write_b128 8-lane group: key = (4(j&1) + (rr>>1)) ^ (j>>1) takes 8 distinct values, so
+//    the (row>>4) term is what makes the wgrad/dgrad staging conflict-free as well.
+SLAM_DEVICE int lds_swz_key(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
+SLAM_DEVICE int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ lds_swz_key(row)) << 4); }
 
 #define HIP_CHECK_RET(expr)                                     \
   do {                                                          \

@@ -150,14 +150,21 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = (acc? out[c]:0) + sum_b part[b][c]
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out,
-                                     int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * N + c];
-  out[c] = s;
+// out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 64 columns x 4 row-slices, fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nb, int N,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < N)
+    for (int b = sl; b < nb; b += 4) s += part[(size_t)b * N + c];
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < N) {
+    float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    out[c] = (accumulate ? out[c] : 0.f) + t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,6 +503,34 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   *reinterpret_cast<uint2*>(d + i) = o;
 }
 
+// dst[C][R] = src[R][C]^T, bf16, 64x64 tiles through LDS (R, C multiples of 64)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C) {
+  __shared__ uint32_t t[64][33];  // 64 rows x 64 bf16 (+1 dword pad)
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = (tid >> 3) + 32 * i, ch = tid & 7;
+    uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + row) * C + c0 + ch * 8);
+    t[row][ch * 4 + 0] = v.x; t[row][ch * 4 + 1] = v.y; t[row][ch * 4 + 2] = v.z; t[row][ch * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int col = (tid >> 3) + 32 * i, rb = tid & 7;  // output row = col, 8 source rows rb*8..
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t a = t[rb * 8 + 2 * k][col >> 1], b = t[rb * 8 + 2 * k + 1][col >> 1];
+      uint32_t lo = (col & 1) ? (a >> 16) : (a & 0xffffu);
+      uint32_t hi = (col & 1) ? (b >> 16) : (b & 0xffffu);
+      w[k] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)(c0 + col) * R + r0 + rb * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 inline unsigned nblocks(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -510,14 +545,14 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
   LAUNCH_RET();
 }
 
-int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }
+int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {
   if ((H & 7) || H > MAXC * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   rmsnorm_bwd_kernel<<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);
-  colsum_finish_kernel<<<(H + 255) / 256, 256, 0, st>>>(part, nb, H, dw, accumulate);
+  colsum_finish_kernel<<<(H + 63) / 64, 256, 0, st>>>(part, nb, H, dw, accumulate);
   LAUNCH_RET();
 }
 
@@ -528,7 +563,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   int nb = colsum_blocks(M);
   dim3 grid((N / 8 + 255) / 256, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
-  colsum_finish_kernel<<<(N + 255) / 256, 256, 0, st>>>(part, nb, N, out, accumulate);
+  colsum_finish_kernel<<<(N + 63) / 64, 256, 0, st>>>(part, nb, N, out, accumulate);
   LAUNCH_RET();
 }
 
@@ -601,6 +636,11 @@ int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const fl
   float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
   adamw_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
                                                      (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  LAUNCH_RET();
+}
+int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
+  if ((R & 63) || (C & 63)) return -1;
+  transpose_bf16_kernel<<<dim3(C / 64, R / 64), 256, 0, st>>>(src, dst, R, C);
   LAUNCH_RET();
 }
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st) {

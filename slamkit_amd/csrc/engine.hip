@@ -48,6 +48,7 @@ struct SlamEngine {
   std::string err;
 
   bf16_t* params = nullptr;
+  bf16_t* params_t = nullptr;  // transposed weight images (optional)
   float* grads = nullptr;
 
   // workspace
@@ -221,6 +222,33 @@ int slam_bind_params(SlamEngine* h, void* params_bf16, float* grads_f32) {
   h->grads = grads_f32;
   return SLAM_OK;
 }
+int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream) {
+  if (!h) return SLAM_EINVAL;
+  if (!h->params_t) return SLAM_OK;
+  if (!h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  hipStream_t st = (hipStream_t)stream;
+  const SlamModelDesc& d = h->d;
+  const bf16_t* P = h->params;
+  bf16_t* Pt = h->params_t;
+  const int H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
+  CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, VPAD, H, st));
+  for (int l = 0; l < d.n_layers; ++l) {
+    const LayerOff& o = h->lo[l];
+    CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, st));
+    CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, st));
+    CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, st));
+    CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, st));
+  }
+  return SLAM_OK;
+}
+int slam_bind_params_t(SlamEngine* h, void* params_t_bf16) {
+  if (!h) return SLAM_EINVAL;
+  const SlamModelDesc& d = h->d;
+  if (params_t_bf16 && ((d.hidden & 63) || (d.intermediate & 63) || (h->QKV & 63) || ((d.n_heads * d.head_dim) & 63)))
+    return h->fail(SLAM_EINVAL, "transposed weight images need dims that are multiples of 64");
+  h->params_t = (bf16_t*)params_t_bf16;
+  return SLAM_OK;
+}
 size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens) {
   if (!h || max_tokens <= 0) return 0;
   SlamEngine tmp;
@@ -315,10 +343,15 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   const bf16_t* P = h->params;
   float* G = h->grads;
 
+  const bf16_t* Pt = h->params_t;
+  // dX[M,K] = dY[M,N] W[N,K]: with a transposed image W^T[K,N] it is the contraction-contiguous form
+  auto dgrad = [&](const bf16_t* dY, int64_t woff, bf16_t* dX, int N, int K) -> int {
+    return Pt ? gemm_nt(dY, Pt + woff, dX, nullptr, nullptr, M, K, N, st) : gemm_nn(dY, P + woff, dX, nullptr, M, N, K, st);
+  };
   if (grad_scale != 1.0f) CK(scale_bf16(h->dlogits, (size_t)M * VPAD, grad_scale, st));
   // tied head: dE += dlogits^T hf ; dhf = dlogits E
   CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, 1, M, VPAD, H, VPAD, H, h->gemm_ws, st));
-  CK(gemm_nn(h->dlogits, P + h->off_embed, h->dx, nullptr, M, VPAD, H, st));
+  CK(dgrad(h->dlogits, h->off_embed, h->dx, VPAD, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
   CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, 1, h->part_ws, M, H, st));
@@ -330,20 +363,20 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     LayerAct& a = h->la[l];
     // MLP
     CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
-    CK(gemm_nn(dh, P + o.wd, h->dact, nullptr, M, H, I, st));
+    CK(dgrad(dh, o.wd, h->dact, H, I));
     CK(swiglu_bwd(a.gu, h->dact, M, I, st));  // a.gu now holds d(gate|up)
     CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
-    CK(gemm_nn(a.gu, P + o.wgu, h->dx, nullptr, M, 2 * I, H, st));
+    CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, G + o.ln2, 1, h->part_ws, M, H, st));
     // attention
     CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
-    CK(gemm_nn(dh2, P + o.wo, h->d_o, nullptr, M, H, HD, st));
+    CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, M, nH, nKV,
                 d.head_dim, st));
     CK(rope_apply(h->dqkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 1, st));
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, G + o.bqkv, 1, h->part_ws, st));
     CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
-    CK(gemm_nn(h->dqkv, P + o.wqkv, h->dx, nullptr, M, h->QKV, H, st));
+    CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, G + o.ln1, 1, h->part_ws, M, H, st));
     if (cb && l > 0 && ((L - l) % bl) == 0) {
       cb(user, o.ln1, bucket_end - o.ln1);
@@ -379,7 +412,7 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
   if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
   CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad,
            (hipStream_t)stream));
-  return SLAM_OK;
+  return slam_refresh_transposed(h, stream);
 }
 
 int slam_zero_grads(SlamEngine* h, slam_stream_t stream) {
@@ -391,7 +424,7 @@ int slam_zero_grads(SlamEngine* h, slam_stream_t stream) {
 int slam_cast_params(SlamEngine* h, const float* master, slam_stream_t stream) {
   if (!h || !master || !h->params) return SLAM_EINVAL;
   CK(f32_to_bf16(master, h->params, (size_t)h->n_params, (hipStream_t)stream));
-  return SLAM_OK;
+  return slam_refresh_transposed(h, stream);
 }
 
 // ---- single-op entry points ------------------------------------------------------------------

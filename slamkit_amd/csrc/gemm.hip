@@ -96,7 +96,7 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
   for (int i = 0; i < 4; ++i) {
     int P = i * 256 + tid;
     int row = P >> 3, cs = P & 7;
-    int c = cs ^ ((row >> 1) & 7);
+    int c = cs ^ lds_swz_key(row);
     int gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
     const bf16_t* src = G + (size_t)gr * ld + k0 + c * 8;
@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   };
 
   // per-lane fragment byte offsets inside a tile (row = 16-aligned base + l15)
-  const int sw = (l15 >> 1) & 7;
+  // swizzle key of row (w*64 + f*16 + l15) = ((l15>>1) ^ (w*4 + f)) & 7 = s0 ^ f
+  const int s0a = ((l15 >> 1) ^ (wn * 4)) & 7;
+  const int s0b = ((l15 >> 1) ^ (wm * 4)) & 7;
   const int a_base = (wn * 64 + l15) * 128;  // a-operand = column (B) tile
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
@@ -179,12 +181,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const char* Bt = At + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((g + 4 * kk) ^ sw) << 4;
+      const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
       uint4 af[4], bf[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + coff);
-        bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + coff);
+        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+        bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
       }
 #pragma unroll
       for (int fm = 0; fm < 4; ++fm)

@@ -58,6 +58,8 @@ def load_library(path: Optional[str] = None):
         "slam_tensor_count": (i32, [vp]),
         "slam_tensor_info": (C.c_int, [vp, i32, C.POINTER(SlamTensorInfo)]),
         "slam_bind_params": (C.c_int, [vp, vp, vp]),
+        "slam_bind_params_t": (C.c_int, [vp, vp]),
+        "slam_refresh_transposed": (C.c_int, [vp, vp]),
         "slam_workspace_bytes": (sz, [vp, i64]),
         "slam_bind_workspace": (C.c_int, [vp, vp, sz, i64]),
         "slam_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
@@ -161,6 +163,13 @@ class Engine:
             assert grads_f32.dtype == torch.float32 and grads_f32.numel() == self.n_params
         self._keep["params"], self._keep["grads"] = params_bf16, grads_f32
         self._ck(self.lib.slam_bind_params(self.h, _ptr(params_bf16), _ptr(grads_f32)))
+
+    def bind_params_t(self, params_t_bf16):
+        self._keep["params_t"] = params_t_bf16
+        self._ck(self.lib.slam_bind_params_t(self.h, _ptr(params_t_bf16)))
+
+    def refresh_transposed(self, stream=None):
+        self._ck(self.lib.slam_refresh_transposed(self.h, stream if stream is not None else current_stream_ptr()))
 
     def workspace_bytes(self, max_tokens: int) -> int:
         return int(self.lib.slam_workspace_bytes(self.h, max_tokens))

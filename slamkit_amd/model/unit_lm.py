@@ -143,6 +143,14 @@ class UnitLM(TokenLM):
             self.flat_master = torch.zeros(n, dtype=torch.float32, device=self.device)
             self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device) if allocate_grads else None
             self.engine.bind_params(self.flat_params, self.flat_grads)
+            b = config.base_config
+            dims = (b["hidden_size"], b["intermediate_size"], b["num_attention_heads"] * b["head_dim"],
+                    (b["num_attention_heads"] + 2 * b["num_key_value_heads"]) * b["head_dim"])
+            self.flat_params_t = None
+            if allocate_grads and all(x % 64 == 0 for x in dims):
+                # transposed weight images so dgrad runs on the LDS-DMA GEMM path (training only)
+                self.flat_params_t = torch.zeros(n, dtype=torch.bfloat16, device=self.device)
+                self.engine.bind_params_t(self.flat_params_t)
             self._ws = None
             self._ws_tokens = 0
             self._ensure_workspace(config.max_tokens)
