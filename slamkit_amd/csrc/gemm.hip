@@ -6,12 +6,17 @@
 //
 //   forward : Y[M,N]  = X[M,K]  · W[N,K]ᵀ      (TA=0, TB=0)   both operands contraction-contiguous
 //   dgrad   : dX[M,K] = dY[M,N] · W[N,K]       (TA=0, TB=1)   B stored [contraction][cols]
+//             (the engine normally runs dgrad as the first form on a transposed weight image)
 //   wgrad   : dW[N,K] = dYᵀ[N,M] · X[M,K]      (TA=1, TB=1)   A stored [contraction][rows]
 //
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 fragments.
 // Both operand tiles live in LDS as [128][64] bf16 with a 16-byte-chunk XOR swizzle (common.h), so
-// the MFMA inner loop is identical for all three forms; only global->LDS staging differs
-// (direct 16-byte copies, LDS-DMA, or an 8x8 in-register transpose).
+// the MFMA inner loop is identical for all forms; only global->LDS staging differs:
+//   * LDS-DMA (global_load_lds_dwordx4 issued from inline asm so that hipcc does not drain it with
+//     vmcnt(0) in front of every ds_read): NSTAGE-deep ring, counted s_waitcnt vmcnt(N), one
+//     barrier per K-step; the swizzle is applied to the per-lane SOURCE address;
+//   * register staging, direct or with an 8x8 in-register transpose (branch-free loads so the
+//     next tile's loads stay in flight across the MFMA block).
 // MFMA roles are swapped (a-operand = column tile, b-operand = row tile) so a lane ends up holding
 // four consecutive output columns of one row -> 8-byte bf16 / 16-byte fp32 stores.
 #include "common.h"
@@ -21,6 +26,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;  // one operand tile: 128 rows x 128 B
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
 struct GemmArgs {
   const bf16_t* A;
@@ -35,45 +41,59 @@ struct GemmArgs {
 };
 
 SLAM_DEVICE uint32_t comp4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+SLAM_DEVICE uint4 sel4(bool ok, const uint4& v) {
+  return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
 
-// ---- direct staging: operand stored [rows][contraction], 4 x 16 B per thread ----------------
-SLAM_DEVICE void load_direct(const bf16_t* G, int ld, int nrows, int row0, int k0, int kend, int tid,
-                             uint4* r) {
+// ---- direct staging: operand stored [rows][contraction], 4 x 16 B per thread. Loads are
+//      unconditional (out-of-range lanes read element 0 and are zeroed at store time) so no
+//      branch / wait separates them. ---------------------------------------------------------
+SLAM_DEVICE uint32_t load_direct(const bf16_t* G, int ld, int nrows, int row0, int k0, int kend, int tid,
+                                 uint4* r) {
+  uint32_t okm = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int q = tid + 256 * i;
     int row = q >> 3, c = q & 7;
     int gr = row0 + row, gk = k0 + c * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gr < nrows && gk < kend) v = *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk);
-    r[i] = v;
+    bool ok = (gr < nrows) & (gk < kend);
+    size_t off = ok ? ((size_t)gr * ld + gk) : 0;
+    r[i] = *reinterpret_cast<const uint4*>(G + off);
+    okm |= (ok ? 1u : 0u) << i;
   }
+  return okm;
 }
-SLAM_DEVICE void store_direct(char* tile, int tid, const uint4* r) {
+SLAM_DEVICE void store_direct(char* tile, int tid, const uint4* r, uint32_t okm) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int q = tid + 256 * i;
     int row = q >> 3, c = q & 7;
-    *reinterpret_cast<uint4*>(tile + lds_tile_off(row, c)) = r[i];
+    *reinterpret_cast<uint4*>(tile + lds_tile_off(row, c)) = sel4((okm >> i) & 1, r[i]);
   }
 }
 
 // ---- transposed staging: operand stored [contraction][rows]; one 8(kc) x 8(rows) unit per thread,
 //      128 units per tile (unit u: rows (u&15)*8.., kc (u>>4)*8..) -------------------------------
-SLAM_DEVICE void load_transposed(const bf16_t* G, int ld, int nrows, int row0, int k0, int kend, int u,
-                                 uint4* r) {
+SLAM_DEVICE uint32_t load_transposed(const bf16_t* G, int ld, int nrows, int row0, int k0, int kend, int u,
+                                     uint4* r) {
   int rb = u & 15, kb = u >> 4;
   int gr = row0 + rb * 8;
+  uint32_t okm = 0;
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     int gk = k0 + kb * 8 + kk;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gk < kend && gr < nrows) v = *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gr);
-    r[kk] = v;
+    bool ok = (gk < kend) & (gr < nrows);
+    size_t off = ok ? ((size_t)gk * ld + gr) : 0;
+    r[kk] = *reinterpret_cast<const uint4*>(G + off);
+    okm |= (ok ? 1u : 0u) << kk;
   }
+  return okm;
 }
-SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* r) {
+SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t okm) {
   int rb = u & 15, kb = u >> 4;
+  uint4 r[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) r[kk] = sel4((okm >> kk) & 1, rin[kk]);
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
     uint32_t w[4];
@@ -87,11 +107,25 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* r) {
   }
 }
 
-// ---- LDS-DMA staging (direct operands only): the LDS image is lane-linear, so the swizzle is
-//      applied to the per-lane SOURCE chunk; rows past the end are clamped (their products only
-//      reach output rows that are never stored). ------------------------------------------------
-SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0, int tid, char* tile) {
-  int wave = tid >> 6;
+// ---- LDS-DMA staging (direct operands only). One global_load_lds_dwordx4 moves 64 lanes x 16 B to
+//      LDS at M0 + lane*16; issued from asm so the compiler's waitcnt insertion does not see it
+//      (we count it ourselves with s_waitcnt vmcnt(N)). Rows past the end are clamped: their
+//      products only reach output rows that are never stored. ---------------------------------
+SLAM_DEVICE void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0, int tid, uint32_t tile_lds) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int P = i * 256 + tid;
@@ -100,15 +134,23 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
     int gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
     const bf16_t* src = G + (size_t)gr * ld + k0 + c * 8;
-    char* dst = tile + (i * 256 + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    uint32_t dst = __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u);
+    glds16(src, dst);
   }
 }
 
-template <bool TA, bool TB, bool F32OUT, bool GLDS>
+template <int N>
+SLAM_DEVICE void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
+template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool GLDS = NSTAGE > 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -135,41 +177,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  uint4 sa[8], sb[8];
-
-  auto stage_load = [&](int t) {
-    const int k0 = kbeg + t * BK;
-    if constexpr (TA && TB) {
-      if (tid < 128) load_transposed(p.A, p.lda, p.R, row0, k0, kend, tid, sa);
-      else load_transposed(p.B, p.ldb, p.Cn, col0, k0, kend, tid - 128, sa);
-    } else {
-      if constexpr (TA) { if (tid < 128) load_transposed(p.A, p.lda, p.R, row0, k0, kend, tid, sa); }
-      else load_direct(p.A, p.lda, p.R, row0, k0, kend, tid, sa);
-      if constexpr (TB) { if (tid < 128) load_transposed(p.B, p.ldb, p.Cn, col0, k0, kend, tid, sb); }
-      else load_direct(p.B, p.ldb, p.Cn, col0, k0, kend, tid, sb);
-    }
-  };
-  auto stage_store = [&](int s) {
-    char* At = smem + s * 2 * TILE_BYTES;
-    char* Bt = At + TILE_BYTES;
-    if constexpr (TA && TB) {
-      if (tid < 128) store_transposed(At, tid, sa);
-      else store_transposed(Bt, tid - 128, sa);
-    } else {
-      if constexpr (TA) { if (tid < 128) store_transposed(At, tid, sa); }
-      else store_direct(At, tid, sa);
-      if constexpr (TB) { if (tid < 128) store_transposed(Bt, tid, sb); }
-      else store_direct(Bt, tid, sb);
-    }
-  };
-  auto stage_glds = [&](int t, int s) {
-    const int k0 = kbeg + t * BK;
-    char* At = smem + s * 2 * TILE_BYTES;
-    glds_tile(p.A, p.lda, p.R, row0, k0, tid, At);
-    glds_tile(p.B, p.ldb, p.Cn, col0, k0, tid, At + TILE_BYTES);
-  };
-
-  // per-lane fragment byte offsets inside a tile (row = 16-aligned base + l15)
   // swizzle key of row (w*64 + f*16 + l15) = ((l15>>1) ^ (w*4 + f)) & 7 = s0 ^ f
   const int s0a = ((l15 >> 1) ^ (wn * 4)) & 7;
   const int s0b = ((l15 >> 1) ^ (wm * 4)) & 7;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
   auto compute = [&](int s) {
-    const char* At = smem + s * 2 * TILE_BYTES;
+    const char* At = smem + s * STAGE_BYTES;
     const char* Bt = At + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -195,18 +202,57 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
   };
 
-  if (nk > 0) {
-    if constexpr (GLDS) {
-      stage_glds(0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage_glds(t + 1, (t + 1) & 1);
-        compute(t & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+  if constexpr (GLDS) {
+    constexpr int D = NSTAGE - 1;  // tiles in flight ahead of the one being computed
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int t) {
+      const int k0 = kbeg + t * BK;
+      const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
+      glds_tile(p.A, p.lda, p.R, row0, k0, tid, st);
+      glds_tile(p.B, p.ldb, p.Cn, col0, k0, tid, st + TILE_BYTES);
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) issue(s);
+    for (int t = 0; t < nk; ++t) {
+      // tile t has landed once at most min(D-1, nk-1-t) later tiles (8 DMAs each) are outstanding
+      const int rem = min(D - 1, nk - 1 - t);
+      if (D >= 3 && rem >= 2) wait_vmcnt<16>();
+      else if (D >= 2 && rem == 1) wait_vmcnt<8>();
+      else wait_vmcnt<0>();
+      __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
+      if (t + D < nk) issue(t + D);
+      compute(t % NSTAGE);
+    }
+  } else {
+    uint4 sa[8], sb[8];
+    uint32_t ma = 0, mb = 0;
+    auto stage_load = [&](int t) {
+      const int k0 = kbeg + t * BK;
+      if constexpr (TA && TB) {
+        if (tid < 128) ma = load_transposed(p.A, p.lda, p.R, row0, k0, kend, tid, sa);
+        else ma = load_transposed(p.B, p.ldb, p.Cn, col0, k0, kend, tid - 128, sa);
+      } else {
+        if constexpr (TA) { if (tid < 128) ma = load_transposed(p.A, p.lda, p.R, row0, k0, kend, tid, sa); }
+        else ma = load_direct(p.A, p.lda, p.R, row0, k0, kend, tid, sa);
+        if constexpr (TB) { if (tid < 128) mb = load_transposed(p.B, p.ldb, p.Cn, col0, k0, kend, tid, sb); }
+        else mb = load_direct(p.B, p.ldb, p.Cn, col0, k0, kend, tid, sb);
       }
-    } else {
+    };
+    auto stage_store = [&](int s) {
+      char* At = smem + s * STAGE_BYTES;
+      char* Bt = At + TILE_BYTES;
+      if constexpr (TA && TB) {
+        if (tid < 128) store_transposed(At, tid, sa, ma);
+        else store_transposed(Bt, tid - 128, sa, ma);
+      } else {
+        if constexpr (TA) { if (tid < 128) store_transposed(At, tid, sa, ma); }
+        else store_direct(At, tid, sa, ma);
+        if constexpr (TB) { if (tid < 128) store_transposed(Bt, tid, sb, mb); }
+        else store_direct(Bt, tid, sb, mb);
+      }
+    };
+    if (nk > 0) {
       stage_load(0);
       stage_store(0);
       __syncthreads();
@@ -219,34 +265,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3] for each (fm, fn) ------------------------------------
+  // ---- epilogue: lane holds C[m][n..n+3] for each (fm, fn); bias / residual loads are batched
+  //      per row so they are all in flight together -------------------------------------------
+  uint2 bb[4];
+  if (!F32OUT && p.bias) {
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      int n = col0 + wn * 64 + fn * 16 + g * 4;
+      bb[fn] = *reinterpret_cast<const uint2*>(p.bias + (n < p.Cn ? n : 0));
+    }
+  }
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
     const int m = row0 + wm * 64 + fm * 16 + l15;
-    if (m >= p.R) continue;
+    const bool mok = m < p.R;
+    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+    if constexpr (F32OUT) {
+      float* Cf = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.R * p.ldc;
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      const int n = col0 + wn * 64 + fn * 16 + g * 4;
-      if (n >= p.Cn) continue;
-      f32x4_t v = acc[fm][fn];
-      if constexpr (F32OUT) {
-        float* Cf = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.R * p.ldc;
-        *reinterpret_cast<float4*>(Cf + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
+      for (int fn = 0; fn < 4; ++fn) {
+        const int n = col0 + wn * 64 + fn * 16 + g * 4;
+        f32x4_t v = acc[fm][fn];
+        if (mok && n < p.Cn) *reinterpret_cast<float4*>(Cf + rowoff + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      uint2 rr[4];
+      if (p.resid) {
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          int n = col0 + wn * 64 + fn * 16 + g * 4;
+          rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + (n < p.Cn ? n : 0));
+        }
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        const int n = col0 + wn * 64 + fn * 16 + g * 4;
+        f32x4_t v = acc[fm][fn];
         if (p.bias) {
-          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + n);
-          v[0] += __uint_as_float(bb.x << 16); v[1] += __uint_as_float(bb.x & 0xffff0000u);
-          v[2] += __uint_as_float(bb.y << 16); v[3] += __uint_as_float(bb.y & 0xffff0000u);
+          v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
+          v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
         }
         if (p.resid) {
-          uint2 rr = *reinterpret_cast<const uint2*>(p.resid + (size_t)m * p.ldc + n);
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+          v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
         }
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]);
         o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
+        if (mok && n < p.Cn) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
       }
     }
   }
@@ -265,10 +331,18 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
-template <bool TA, bool TB, bool F32OUT, bool GLDS>
+template <bool TA, bool TB, bool F32OUT, int NSTAGE>
 int launch(const GemmArgs& a, int splits, hipStream_t st) {
+  constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, GLDS><<<grid, 256, 0, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, NSTAGE><<<grid, 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -276,8 +350,9 @@ int launch(const GemmArgs& a, int splits, hipStream_t st) {
 
 namespace slam {
 
-static int g_gemm_glds = 1;
-void gemm_set_glds(int on) { g_gemm_glds = on; }
+// gemm_glds: 0 = register staging, 2/3/4 = LDS-DMA ring depth
+static int g_gemm_glds = 2;
+void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
 
 static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
   if (R <= 0 || Cn <= 0 || Kc <= 0) return -1;
@@ -291,8 +366,14 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   if (check_dims(M, N, K, K, K, N) || (K & 7)) return -1;
   GemmArgs a{X, W, Y, bias, resid, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (N + BN - 1) / BN};
-  bool glds = g_gemm_glds && (K % BK == 0) && (N % BN == 0);
-  return glds ? launch<false, false, false, true>(a, 1, st) : launch<false, false, false, false>(a, 1, st);
+  const bool dma_ok = (K % BK == 0) && (N % BN == 0);
+  const int mode = dma_ok ? g_gemm_glds : 0;
+  switch (mode) {
+    case 2: return launch<false, false, false, 2>(a, 1, st);
+    case 3: return launch<false, false, false, 3>(a, 1, st);
+    case 4: return launch<false, false, false, 4>(a, 1, st);
+    default: return launch<false, false, false, 0>(a, 1, st);
+  }
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+resid[M,K]); contraction over N.
@@ -301,7 +382,7 @@ int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, 
   if (check_dims(M, K, N, N, K, K) || (N & 7)) return -1;
   GemmArgs a{dY, W, dX, nullptr, resid, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (K + BN - 1) / BN};
-  return launch<false, true, false, false>(a, 1, st);
+  return launch<false, true, false, 0>(a, 1, st);
 }
 
 int gemm_tn_splits(int M, int N, int K) {
@@ -325,7 +406,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
   GemmArgs a{dY, X, ws, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
-  int e = launch<true, true, true, false>(a, splits, st);
+  int e = launch<true, true, true, 0>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
   reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate);
