@@ -1,0 +1,124 @@
+"""Host-side pipeline (tokeniser -> prepare_tokens -> dataset -> collators) against the golden
+vectors captured from the real reference (bit-exact: integer work)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from slamkit_amd.data import (DataCollatorForLanguageModeling, DataCollatorWithFlattening, TokenShardDataset,
+                              chunk_texts, init_dataset, write_token_shard, get_filter_fn, interleave_datasets,
+                              TokenDataset)
+from slamkit_amd.tokeniser import UnitTokeniser, tokeniser_factory
+from slamkit_amd.utils.config import load_config, to_config
+
+
+def _tok():
+    return tokeniser_factory(to_config({"tokeniser_type": "unit", "feature_extractor": {"num_units": 500},
+                                       "params": {"dedup": True, "bos_eos_token_id": 1, "load_fe": False}}))
+
+
+def test_unit_tokeniser_known_answers(golden_data):
+    tok = _tok()
+    assert len(tok.text_tokeniser) == golden_data["vocab_size"] == 502
+    for row in golden_data["G1_tokens"]:
+        assert tok.stringify_representation([{"units": row["units"]}], mode="train")[0] == row["audio_repr"]
+        enc = tok.prepare_sample({"audio_repr": row["audio_repr"]})
+        assert list(enc["input_ids"]) == row["input_ids"]
+        assert list(enc["attention_mask"]) == row["attention_mask"]
+        ids = torch.tensor(row["input_ids"])
+        assert tok.decode_sample(ids).tolist() == row["units"]
+    # batch / padded form used by tokenise()
+    enc = tok.string_tokenise([r["audio_repr"] for r in golden_data["G1_tokens"]], return_tensors="pt", padding=True)
+    assert enc["input_ids"].shape == (2, 330) and int(enc["attention_mask"][1].sum()) == 290
+
+
+def test_tokeniser_save_load(tmp_path):
+    tok = _tok()
+    tok.save_pretrained(str(tmp_path))
+    t2 = UnitTokeniser.from_pretrained(str(tmp_path))
+    assert t2.num_units == 500 and t2.pad_token_id == 0 and t2.bos_token_id == 1 and t2.model is None
+
+
+def test_prepare_tokens_cli(golden_data, tmp_path):
+    from slamkit_amd.cli.prepare_tokens import prepare_tokens
+    feats = tmp_path / "features.jsonl"
+    with open(feats, "w") as f:
+        for i, row in enumerate(golden_data["G1_tokens"]):
+            f.write(json.dumps({"file_name": f"a{i}.flac", "units": row["units"], "duration": [1] * len(row["units"])}) + "\n")
+    out = prepare_tokens([f"data_path={feats}", f"out_path={tmp_path}/out"])
+    rows = [json.loads(l) for l in open(out)]
+    assert [r["audio_repr"] for r in rows] == [g["audio_repr"] for g in golden_data["G1_tokens"]]
+    assert all("units" not in r and "duration" not in r for r in rows)
+
+
+def _write_tokens(golden_data, path):
+    with open(path, "w") as f:
+        for i, row in enumerate(golden_data["G1_tokens"]):
+            f.write(json.dumps({"file_name": f"a{i}.flac", "audio_repr": row["audio_repr"]}) + "\n")
+
+
+def test_init_dataset_chunks_and_collators(golden_data, tmp_path):
+    p = tmp_path / "tokens.jsonl"
+    _write_tokens(golden_data, p)
+    cfg = to_config({"data": {"train_path": str(p), "val_path": str(p), "packing": False},
+                     "model": {"context_len": 128}})
+    ds, coll = init_dataset(cfg, _tok())
+    exp = golden_data["G2_chunks"]["128"]
+    assert [r["input_ids"] for r in ds["train"].rows] == exp["input_ids"]
+    assert [r["attention_mask"] for r in ds["train"].rows] == exp["attention_mask"]
+    assert [len(r["input_ids"]) for r in ds["validation"].rows] == [128, 128, 74, 128, 128, 34]
+    batch = coll([ds["train"][i] for i in (1, 2, 3)])
+    for k, v in golden_data["G3_lm"].items():
+        assert batch[k].tolist() == v, k
+    cfg.data.packing = True
+    _, coll2 = init_dataset(cfg, _tok())
+    assert isinstance(coll2, DataCollatorWithFlattening)
+    flat = coll2([ds["train"][i] for i in (1, 2, 3)])
+    for k in ("input_ids", "position_ids", "labels"):
+        assert flat[k].tolist() == golden_data["G3_flat"][k], k
+    # chunk length filters (hf_dataset.py:69-88, 102-113)
+    cfg.data.packing = False
+    cfg.data["chunk_units_min_length"] = 100
+    ds2, _ = init_dataset(cfg, _tok())
+    assert [len(r["input_ids"]) for r in ds2["train"].rows] == [128, 128, 128, 128]
+    assert get_filter_fn(sample_units_max_length=300)({"input_ids": [0] * 290})
+
+
+def test_binary_shard_roundtrip_and_saved_ds_path(golden_data, tmp_path):
+    p = tmp_path / "tokens.jsonl"
+    _write_tokens(golden_data, p)
+    saved = tmp_path / "cache"
+    cfg = to_config({"data": {"train_path": str(p), "val_path": None, "packing": False, "saved_ds_path": str(saved)},
+                     "model": {"context_len": 512}})
+    ds, _ = init_dataset(cfg, _tok())
+    assert os.path.exists(saved / "train" / "tokens.bin")
+    ds2, _ = init_dataset(cfg, _tok())  # second call loads the uint16 shard
+    assert isinstance(ds2["train"], TokenShardDataset) and len(ds2["train"]) == len(ds["train"])
+    for i in range(len(ds["train"])):
+        assert ds2["train"][i] == ds["train"][i]
+    assert ds2["train"].num_tokens == 620
+    raw = np.fromfile(saved / "train" / "tokens.bin", dtype="<u2")
+    assert raw[:6].tolist() == [1, 5, 51, 9, 256, 32]  # <S> + unit+2
+
+
+def test_interleave_datasets_is_seeded_and_stops_first_exhausted():
+    a = TokenDataset([{"input_ids": [i], "attention_mask": [1]} for i in range(10)])
+    b = TokenDataset([{"input_ids": [100 + i], "attention_mask": [1]} for i in range(4)])
+    x = interleave_datasets([a, b], [0.5, 0.5], seed=0)
+    y = interleave_datasets([a, b], [0.5, 0.5], seed=0)
+    assert x.rows == y.rows
+    na = sum(1 for r in x.rows if r["input_ids"][0] < 100)
+    nb = len(x) - na
+    assert na == 10 or nb == 4
+
+
+def test_config_loader_matches_reference_hyperparameters():
+    cfg = load_config("train", ["data.train_path=/x/*.jsonl", "training_args.max_steps=7", "model=slam"])
+    assert cfg.model.context_len == 1024 and cfg.model.config_args.rope_theta == 10000
+    assert cfg.model.config_args.base_model_name == "Qwen/Qwen2.5-0.5B" and cfg.model.tlm_type == "twist"
+    ta = cfg.training_args
+    assert (ta.learning_rate, ta.lr_scheduler_kwargs["min_lr"], ta.max_grad_norm, ta.warmup_steps) == (1e-3, 5e-5, 0.5, 100)
+    assert ta.per_device_train_batch_size == 8 and ta.max_steps == 7 and ta.bf16 is True
+    assert cfg.tokeniser.params.load_fe is False and cfg.data.train_path == "/x/*.jsonl"
+    assert load_config("train", ["model=default"]).model.context_len == 512
