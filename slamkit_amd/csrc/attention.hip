@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float mrun[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
+  const int segmax_w = p.seg_start[min(qw0 + 31, M - 1)];  // wave-uniform: latest segment start among its rows
 
   const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
   const int kt_end = (min(q0 + 127, M - 1)) / 64;
@@ -142,31 +143,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
           for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
         }
       uint4 pb[2][2];
+      // mrun is kept in raw-score units; p = exp2(s*c2 - m*c2) is one FMA + one v_exp per element.
+      // Per-element masking only on tiles that cross the diagonal or a segment start (wave-uniform).
+      const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float mx = NEG_BIG;
-        bool ok[4][4];
+        if (need_mask) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int key = key0 + f * 16 + g * 4 + r;
+              bool ok = (key <= qrow[j]) && (key >= segs[j]);
+              st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
+            }
+        }
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int key = key0 + f * 16 + g * 4 + r;
-            ok[f][r] = (key <= qrow[j]) && (key >= segs[j]);
-            float s = ok[f][r] ? st[f][j][r] * c2 : NEG_BIG;
-            st[f][j][r] = s;
-            mx = fmaxf(mx, s);
-          }
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(mrun[j], mx);
-        const float alpha = exp2f(mrun[j] - mnew);
+        const float alpha = exp2f((mrun[j] - mnew) * c2);
         mrun[j] = mnew;
+        const float mc = mnew * c2;
         float ps = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float e = ok[f][r] ? exp2f(st[f][j][r] - mnew) : 0.f;
+            // masked entries are NEG_BIG: exp2 underflows to 0 unless the whole row is still masked
+            // (mnew == NEG_BIG), which the explicit select below handles
+            float e = exp2f(fmaf(st[f][j][r], c2, -mc));
+            if (need_mask) e = (st[f][j][r] <= 0.5f * NEG_BIG) ? 0.f : e;
             st[f][j][r] = e;
             ps += e;
           }
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         o.y = pack_bf16x2(ot[fd][j][2] * inv, ot[fd][j][3] * inv);
         *reinterpret_cast<uint2*>(p.o + (size_t)q * (p.nH * 64) + h * 64 + fd * 16 + g * 4) = o;
       }
-      if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = mrun[j] + log2f(l);
+      if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = mrun[j] * c2 + log2f(l);
     }
   }
 }
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const int seg = p.seg_start[qc];
   const float lse = p.lse2[(size_t)h * M + qc];
   const float dsm = p.dsum[(size_t)h * M + qc];
+  const int segmax_w = p.seg_start[min(qw0 + 15, M - 1)];
   uint4 qf[2], dof[2];
 #pragma unroll
   for (int ds = 0; ds < 2; ++ds) {
@@ -288,13 +300,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
           st[f] = mfma16(frag_direct(Ks, f, l15, g, ds), qf[ds], st[f]);
           dp[f] = mfma16(frag_direct(Vs, f, l15, g, ds), dof[ds], dp[f]);
         }
+      const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + 15 >= M);
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int key = key0 + f * 16 + g * 4 + r;
-          bool ok = (key <= q) && (key >= seg) && (q < M);
-          float pe = ok ? exp2f(st[f][r] * c2 - lse) : 0.f;
+          float pe = exp2f(fmaf(st[f][r], c2, -lse));
+          if (need_mask) {
+            int key = key0 + f * 16 + g * 4 + r;
+            bool ok = (key <= q) && (key >= seg) && (q < M);
+            pe = ok ? pe : 0.f;
+          }
           st[f][r] = pe * (dp[f][r] - dsm);
         }
       uint4 dsb[2] = {pack_pair(st[0], st[1]), pack_pair(st[2], st[3])};
@@ -385,7 +401,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
           s[jq] = mfma16(frag_direct(Qs, jq, l15, g, ds), kf[ds], s[jq]);
           dp[jq] = mfma16(frag_direct(dOs, jq, l15, g, ds), vf[ds], dp[jq]);
         }
-      // lane holds (q = qbase + jq*16 + 4g + r, key)
+      // lane holds (q = qbase + jq*16 + 4g + r, key); mask only on diagonal / segment-boundary / tail tiles
+      const int kw0 = k0 + wave * 16;
+      const bool need_mask = (kw0 + 15 > qbase) || (kw0 < seg_s[63]) || (qbase + 63 >= M);
 #pragma unroll
       for (int jq = 0; jq < 4; ++jq) {
         const float4 l4 = *reinterpret_cast<const float4*>(lse_s + jq * 16 + g * 4);
@@ -395,9 +413,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int qq = qbase + jq * 16 + g * 4 + r;
-          bool ok = (key <= qq) && (key >= sv[r]);
-          float pe = ok ? exp2f(s[jq][r] * c2 - lv[r]) : 0.f;
+          float pe = exp2f(fmaf(s[jq][r], c2, -lv[r]));
+          if (need_mask) {
+            int qq = qbase + jq * 16 + g * 4 + r;
+            bool ok = (key <= qq) && (key >= sv[r]);
+            pe = ok ? pe : 0.f;
+          }
           s[jq][r] = pe;
           dp[jq][r] = pe * (dp[jq][r] - dvv[r]);
         }
