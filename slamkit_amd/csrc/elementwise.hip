@@ -150,19 +150,21 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 64 columns x 4 row-slices, fixed order
+// out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 16 columns x 16 row-slices, fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nb, int N,
                                                             float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
   if (c < N)
-    for (int b = sl; b < nb; b += 4) s += part[(size_t)b * N + c];
+    for (int b = sl; b < nb; b += 16) s += part[(size_t)b * N + c];
   red[sl][cl] = s;
   __syncthreads();
   if (sl == 0 && c < N) {
-    float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
     out[c] = (accumulate ? out[c] : 0.f) + t;
   }
 }
@@ -545,14 +547,14 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
   LAUNCH_RET();
 }
 
-int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
+int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 256 ? 256 : (b < 1 ? 1 : b); }  // 1 block/CU
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {
   if ((H & 7) || H > MAXC * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   rmsnorm_bwd_kernel<<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);
-  colsum_finish_kernel<<<(H + 63) / 64, 256, 0, st>>>(part, nb, H, dw, accumulate);
+  colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate);
   LAUNCH_RET();
 }
 
@@ -563,7 +565,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   int nb = colsum_blocks(M);
   dim3 grid((N / 8 + 255) / 256, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
-  colsum_finish_kernel<<<(N + 63) / 64, 256, 0, st>>>(part, nb, N, out, accumulate);
+  colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate);
   LAUNCH_RET();
 }
 

@@ -271,6 +271,8 @@ int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_token
 int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!key) return SLAM_EINVAL;
   if (!strcmp(key, "gemm_glds")) { gemm_set_glds((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn_dma")) { gemm_set_tn_dma((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
 }
 

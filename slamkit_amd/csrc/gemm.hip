@@ -139,6 +139,34 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
   }
 }
 
+// ---- transposed operands through LDS-DMA + hardware transpose reads (wgrad). The operand is
+//      stored [contraction][rows] in global memory and lands in LDS the same way ([64 kc][128 rows],
+//      256-B rows); ds_read_b64_tr_b16 then hands lane c of each 16-lane group four consecutive kc
+//      values of row c (measured semantics, tools/probes/tr_probe.hip: out[lane c][j] =
+//      in[lane 4j + (c>>2)][c&3], every lane supplying the address of 4 contiguous bf16).
+//      32-byte row-blocks are XOR-swizzled with key(kc) = (kc&3) | ((kc>>3)&1)<<2 so the 8 kc rows
+//      a 32-lane group touches fall into 8 distinct 32-B windows of the 256-B bank row. ----------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+SLAM_DEVICE int tr_key(int kc) { return (kc & 3) | (((kc >> 3) & 1) << 2); }
+
+SLAM_DEVICE void glds_tile_tr(const bf16_t* G, int ld, int k0, int row0, int tid, uint32_t tile_lds) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int P = i * 256 + tid;
+    int kc = P >> 4, cs = P & 15;
+    int c = cs ^ (tr_key(kc) << 1);
+    const bf16_t* src = G + (size_t)(k0 + kc) * ld + row0 + c * 8;
+    uint32_t dst = __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u);
+    glds16(src, dst);
+  }
+}
+
+SLAM_DEVICE uint2 lds_tr_read(const char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
 template <int N>
 SLAM_DEVICE void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,14 +230,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
   };
 
+  // transposed-operand fragments: lane (l15, g) of fragment P (16 rows) at k-step kk reads
+  // kc = kk*32 + g*8 + h*4 + (l15>>2), 8 bytes at row-block (P ^ key) and sub-offset (l15&3)*8
+  const int trk = (l15 >> 2) | ((g & 1) << 2);
+  const int tr_lane = (g * 8 + (l15 >> 2)) * 256 + (l15 & 3) * 8;
+  auto compute_tr = [&](int s) {
+    const char* At = smem + s * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[4], bf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const char* pa = Bt + tr_lane + kk * 32 * 256 + (((wn * 4 + f) ^ trk) << 5);
+        const char* pb = At + tr_lane + kk * 32 * 256 + (((wm * 4 + f) ^ trk) << 5);
+        uint2 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * 256);
+        uint2 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * 256);
+        af[f] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        bf[f] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+      }
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+    }
+  };
+
   if constexpr (GLDS) {
     constexpr int D = NSTAGE - 1;  // tiles in flight ahead of the one being computed
+    constexpr bool TR = TA && TB;  // both operands stored [contraction][rows]: DMA + transpose reads
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
       const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
-      glds_tile(p.A, p.lda, p.R, row0, k0, tid, st);
-      glds_tile(p.B, p.ldb, p.Cn, col0, k0, tid, st + TILE_BYTES);
+      if constexpr (TR) {
+        glds_tile_tr(p.A, p.lda, k0, row0, tid, st);
+        glds_tile_tr(p.B, p.ldb, k0, col0, tid, st + TILE_BYTES);
+      } else {
+        glds_tile(p.A, p.lda, p.R, row0, k0, tid, st);
+        glds_tile(p.B, p.ldb, p.Cn, col0, k0, tid, st + TILE_BYTES);
+      }
     };
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -222,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       else wait_vmcnt<0>();
       __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
       if (t + D < nk) issue(t + D);
-      compute(t % NSTAGE);
+      if constexpr (TR) compute_tr(t % NSTAGE);
+      else compute(t % NSTAGE);
     }
   } else {
     uint4 sa[8], sb[8];
@@ -352,7 +413,9 @@ namespace slam {
 
 // gemm_glds: 0 = register staging, 2/3/4 = LDS-DMA ring depth
 static int g_gemm_glds = 2;
+static int g_gemm_tn_dma = 1;
 void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
+void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
 
 static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
   if (R <= 0 || Cn <= 0 || Kc <= 0) return -1;
@@ -385,9 +448,14 @@ int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, 
   return launch<false, true, false, 0>(a, 1, st);
 }
 
+static int g_tn_splits_override = 0;
+void gemm_set_tn_splits(int s) { g_tn_splits_override = s; }
 int gemm_tn_splits(int M, int N, int K) {
+  if (g_tn_splits_override > 0) return g_tn_splits_override;
   int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int s = (768 + tiles - 1) / tiles;
+  // measured on MI355X (tools/gemm_bench.py split sweep): ~380 blocks for the few-tile weights
+  // (wqkv 63 tiles -> 6, wo 49 -> 8), ~800 for the big ones (wd 266 -> 3, wgu 532 -> 2)
+  int s = tiles < 128 ? (380 + tiles / 2) / tiles : (800 + tiles / 2) / tiles;
   int maxs = (M + 511) / 512;  // at least 8 k-steps per slice
   if (s > maxs) s = maxs;
   if (s > 32) s = 32;
@@ -406,7 +474,8 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
   GemmArgs a{dY, X, ws, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
-  int e = launch<true, true, true, 0>(a, splits, st);
+  const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
+  int e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
   reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate);

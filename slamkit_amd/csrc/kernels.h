@@ -10,6 +10,8 @@ namespace slam {
 
 // gemm.hip
 void gemm_set_glds(int on);
+void gemm_set_tn_dma(int on);
+void gemm_set_tn_splits(int s);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,

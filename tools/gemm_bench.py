@@ -43,5 +43,9 @@ for name, (N, K) in {"wqkv": (1152, 896), "wo": (896, 896), "wgu": (9728, 896), 
     dy, x = rb(M, N), rb(M, K)
     ws = torch.empty(lib.slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device=dev)
     dw = torch.zeros(N, K, dtype=torch.float32, device=dev)
-    us = timeit(lambda: lib.slam_op_gemm_tn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 1, M, N, K, ws.data_ptr(), st))
-    print(f"tn {name:25s} {'-':>5s} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
+    ws = torch.empty(32 * N * K + 16, dtype=torch.float32, device=dev)
+    for sp in (0, 1, 2, 3, 4, 6, 8, 10, 12, 16):
+        lib.slam_set_option(None, b"gemm_tn_splits", sp)
+        us = timeit(lambda: lib.slam_op_gemm_tn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 1, M, N, K, ws.data_ptr(), st))
+        print(f"tn {name:25s} S={sp:3d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
+    lib.slam_set_option(None, b"gemm_tn_splits", 0)
