@@ -7,19 +7,21 @@
 // Replaces Qwen2Attention's softmax_fp32(QKᵀ/8 + mask)·V (site-packages
 // transformers/models/qwen2/modeling_qwen2.py:138-172) and its autograd; SURVEY.md §8a T5.
 //
-// All three kernels keep the softmax tile in registers: scores are produced *transposed*
-// (MFMA a-operand = keys, b-operand = queries, or vice versa in dKV) so that the contraction
-// index of the following MFMA already sits in the (lane>>4, reg) position of the C fragment and
-// the bf16 P / dS fragment is fed straight back as an MFMA operand - no LDS round trip.
-// The matching operand is read from a transposed LDS image ([d][row], 136-byte pitch).
+// Structure shared by the three MFMA kernels:
+//  * scores are produced TRANSPOSED (a-operand = keys, b-operand = queries, or vice versa in dKV)
+//    so the contraction index of the following MFMA already sits in the (lane>>4, reg) position
+//    of the C fragment and the bf16 P / dS fragment is fed straight back as an MFMA operand;
+//  * every 64x64 operand tile arrives by LDS-DMA (global_load_lds_dwordx4, counted vmcnt, ring of
+//    stages, ONE barrier per tile, no register staging): a "D image" (16-B chunk swizzle, read
+//    with ds_read_b128 when the contraction runs along head_dim) and/or a "T image" (32-B block
+//    swizzle, read with ds_read_b64_tr_b16 when the contraction runs along the rows);
+//  * per-element masking only on tiles that touch the diagonal, a segment start or the tail.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int XT_PITCH = 136;              // bytes per d-row of a transposed 64x64 tile
-constexpr int XT_BYTES = 64 * XT_PITCH;    // 8704
-constexpr int DT_BYTES = 64 * 128;         // direct 64x64 tile
+constexpr int IMG = 64 * 128;  // one 64x64 bf16 LDS image
 constexpr float NEG_BIG = -1.0e30f;
 
 struct AttnArgs {
@@ -36,40 +38,32 @@ struct AttnArgs {
   float scale;         // head_dim^-0.5
 };
 
-// thread -> (row pair p, chunk dc) mapping for 64x64 tiles: rows 2p, 2p+1, 16-byte chunk dc
-SLAM_DEVICE void tile_load(const bf16_t* base, int ld, int row0, int M, int tid, uint4& r0, uint4& r1) {
-  int p = tid >> 3, dc = tid & 7;
-  int g0 = row0 + 2 * p;
-  r0 = make_uint4(0, 0, 0, 0);
-  r1 = r0;
-  if (g0 < M) r0 = *reinterpret_cast<const uint4*>(base + (size_t)g0 * ld + dc * 8);
-  if (g0 + 1 < M) r1 = *reinterpret_cast<const uint4*>(base + (size_t)(g0 + 1) * ld + dc * 8);
-}
-SLAM_DEVICE void tile_store_direct(char* tile, int tid, const uint4& r0, const uint4& r1) {
-  int p = tid >> 3, dc = tid & 7;
-  *reinterpret_cast<uint4*>(tile + lds_tile_off(2 * p, dc)) = r0;
-  *reinterpret_cast<uint4*>(tile + lds_tile_off(2 * p + 1, dc)) = r1;
-}
-SLAM_DEVICE void tile_store_transposed(char* xt, int tid, const uint4& r0, const uint4& r1) {
-  int p = tid >> 3, dc = tid & 7;
-  const uint32_t a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+// DMA one 64x64 tile (rows row0.., clamped to M-1) into an LDS image; 2 x 16 B per thread.
+template <bool TIMG>
+SLAM_DEVICE void dma_tile64(const bf16_t* base, int ld, int row0, int M, int tid, uint32_t img) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint32_t x = a[i >> 1], y = b[i >> 1];
-    uint32_t w = (i & 1) ? ((x >> 16) | (y & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
-    *reinterpret_cast<uint32_t*>(xt + (dc * 8 + i) * XT_PITCH + p * 4) = w;
+  for (int i = 0; i < 2; ++i) {
+    int P = i * 256 + tid;
+    int row = P >> 3, cs = P & 7;
+    int c = TIMG ? ((((cs >> 1) ^ ((row >> 1) & 3)) << 1) | (cs & 1)) : (cs ^ lds_swz_key(row));
+    int gr = min(row0 + row, M - 1);
+    const bf16_t* src = base + (size_t)gr * ld + c * 8;
+    glds16(src, __builtin_amdgcn_readfirstlane(img + (uint32_t)(i * 256 + wave * 64) * 16u));
   }
 }
-// a-operand fragment from a direct tile: row = f*16 + l15, d-block g + 4*ds
-SLAM_DEVICE uint4 frag_direct(const char* tile, int f, int l15, int g, int ds) {
-  return *reinterpret_cast<const uint4*>(tile + lds_tile_off(f * 16 + l15, g + 4 * ds));
+// a-operand fragment from a D image: row = f*16 + l15, head_dim block g + 4*ds
+SLAM_DEVICE uint4 frag_direct(const char* img, int f, int l15, int g, int ds) {
+  return *reinterpret_cast<const uint4*>(img + lds_tile_off(f * 16 + l15, g + 4 * ds));
 }
-// a-operand fragment from a transposed tile for contraction step t: d = fd*16 + l15,
-// rows {32t + 4g + r} U {32t + 16 + 4g + r}, r = 0..3 (the order the P/dS b-operand is packed in)
-SLAM_DEVICE uint4 frag_transposed(const char* xt, int fd, int l15, int g, int t) {
-  const char* base = xt + (fd * 16 + l15) * XT_PITCH + (32 * t + 4 * g) * 2;
-  uint2 lo = *reinterpret_cast<const uint2*>(base);
-  uint2 hi = *reinterpret_cast<const uint2*>(base + 32);
+// a-operand fragment from a T image for contraction step t: column d = fd*16 + l15, rows
+// {32t + 4g + r} U {32t + 16 + 4g + r}, r = 0..3 (the order the P / dS b-operand is packed in).
+// Lane (l15, g) addresses row 32t + 4g + (l15>>2), columns fd*16 + 4(l15&3)..+3; the 32-B block
+// index is XORed with (row>>1)&3 = ((g&1)<<1)|(l15>>3) so a 32-lane group hits 8 distinct windows.
+SLAM_DEVICE uint4 frag_tr(const char* img, int fd, int l15, int g, int t) {
+  const int k2 = ((g & 1) << 1) | (l15 >> 3);
+  const char* p = img + (32 * t + 4 * g + (l15 >> 2)) * 128 + ((fd ^ k2) << 5) + (l15 & 3) * 8;
+  uint2 lo = lds_tr_read(p), hi = lds_tr_read(p + 16 * 128);
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
@@ -79,10 +73,10 @@ SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
 
 // ------------------------------------------------------------------------------------------
 // Forward. grid (ceil(M/128), nH); wave w owns query rows q0+32w .. +31 (two 16-row fragments).
+// Stage = K D-image + V T-image (16 KB), 3-stage ring, 4 DMAs per lane per tile.
+constexpr int FWD_NST = 3;
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[DT_BYTES + XT_BYTES];
-  char* Ks = smem;
-  char* Vt = smem + DT_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
@@ -93,6 +87,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
   const float c2 = p.scale * 1.44269504088896340736f;
+  const uint32_t lds0 = lds_addr(smem);
+
+  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
+  const int kt_end = (min(q0 + 127, M - 1)) / 64;
+  const int n = kt_end - kt_begin + 1;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % FWD_NST) * 2 * IMG);
+    dma_tile64<false>(Kb, ld, (kt_begin + t) * 64, M, tid, st);
+    dma_tile64<true>(Vb, ld, (kt_begin + t) * 64, M, tid, st + IMG);
+  };
+#pragma unroll
+  for (int s = 0; s < FWD_NST - 1; ++s)
+    if (s < n) issue(s);
 
   int qrow[2], segs[2];
   uint4 qf[2][2];
@@ -106,99 +113,89 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int ds = 0; ds < 2; ++ds)
       qf[j][ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
   }
+  const int segmax_w = p.seg_start[min(qw0 + 31, M - 1)];  // latest segment start among the wave's rows
   f32x4_t ot[4][2];
 #pragma unroll
   for (int fd = 0; fd < 4; ++fd)
 #pragma unroll
     for (int j = 0; j < 2; ++j) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float mrun[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
-  const int segmax_w = p.seg_start[min(qw0 + 31, M - 1)];  // wave-uniform: latest segment start among its rows
+  float mrun[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};  // running max in raw-score units
 
-  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
-  const int kt_end = (min(q0 + 127, M - 1)) / 64;
-  uint4 kr0, kr1, vr0, vr1;
-  tile_load(Kb, ld, kt_begin * 64, M, tid, kr0, kr1);
-  tile_load(Vb, ld, kt_begin * 64, M, tid, vr0, vr1);
-  for (int kt = kt_begin; kt <= kt_end; ++kt) {
-    tile_store_direct(Ks, tid, kr0, kr1);
-    tile_store_transposed(Vt, tid, vr0, vr1);
+  for (int t = 0; t < n; ++t) {
+    if (n - 1 - t >= 1) wait_vmcnt<4>();  // tile t landed once at most one later tile (4 DMAs) is in flight
+    else wait_vmcnt<0>();
     __syncthreads();
-    if (kt < kt_end) {
-      tile_load(Kb, ld, (kt + 1) * 64, M, tid, kr0, kr1);
-      tile_load(Vb, ld, (kt + 1) * 64, M, tid, vr0, vr1);
-    }
-    const int key0 = kt * 64;
-    if (key0 <= qw0 + 31) {  // wave-uniform: tile not entirely above this wave's diagonal
-      f32x4_t st[4][2];
+    if (t + FWD_NST - 1 < n) issue(t + FWD_NST - 1);
+    const char* Ks = smem + (t % FWD_NST) * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    const int key0 = (kt_begin + t) * 64;
+    if (key0 > qw0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
+    f32x4_t st[4][2];
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j) st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          uint4 kf = frag_direct(Ks, f, l15, g, ds);
+      for (int f = 0; f < 4; ++f) {
+        uint4 kf = frag_direct(Ks, f, l15, g, ds);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
-        }
-      uint4 pb[2][2];
-      // mrun is kept in raw-score units; p = exp2(s*c2 - m*c2) is one FMA + one v_exp per element.
-      // Per-element masking only on tiles that cross the diagonal or a segment start (wave-uniform).
-      const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w);
+        for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
+      }
+    uint4 pb[2][2];
+    const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float mx = NEG_BIG;
-        if (need_mask) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int key = key0 + f * 16 + g * 4 + r;
-              bool ok = (key <= qrow[j]) && (key >= segs[j]);
-              st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun[j], mx);
-        const float alpha = exp2f((mrun[j] - mnew) * c2);
-        mrun[j] = mnew;
-        const float mc = mnew * c2;
-        float ps = 0.f;
+    for (int j = 0; j < 2; ++j) {
+      float mx = NEG_BIG;
+      if (need_mask) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            // masked entries are NEG_BIG: exp2 underflows to 0 unless the whole row is still masked
-            // (mnew == NEG_BIG), which the explicit select below handles
-            float e = exp2f(fmaf(st[f][j][r], c2, -mc));
-            if (need_mask) e = (st[f][j][r] <= 0.5f * NEG_BIG) ? 0.f : e;
-            st[f][j][r] = e;
-            ps += e;
+            int key = key0 + f * 16 + g * 4 + r;
+            bool ok = (key <= qrow[j]) && (key >= segs[j]);
+            st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
           }
-        lsum[j] = lsum[j] * alpha + ps;
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
-        pb[0][j] = pack_pair(st[0][j], st[1][j]);
-        pb[1][j] = pack_pair(st[2][j], st[3][j]);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) {
-          uint4 vf = frag_transposed(Vt, fd, l15, g, t);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[j], mx);
+      const float alpha = exp2f((mrun[j] - mnew) * c2);
+      mrun[j] = mnew;
+      const float mc = mnew * c2;
+      float ps = 0.f;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf, pb[t][j], ot[fd][j]);
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // masked entries are NEG_BIG: exp2 underflows to 0 unless the whole row is still masked
+          // (mnew == NEG_BIG), which the explicit select handles
+          float e = exp2f(fmaf(st[f][j][r], c2, -mc));
+          if (need_mask) e = (st[f][j][r] <= 0.5f * NEG_BIG) ? 0.f : e;
+          st[f][j][r] = e;
+          ps += e;
         }
+      lsum[j] = lsum[j] * alpha + ps;
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+      pb[0][j] = pack_pair(st[0][j], st[1][j]);
+      pb[1][j] = pack_pair(st[2][j], st[3][j]);
     }
-    __syncthreads();
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        uint4 vf = frag_tr(Vs, fd, l15, g, t2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf, pb[t2][j], ot[fd][j]);
+      }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -242,11 +239,10 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
+// Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
+constexpr int DQ_NST = 3;
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * DT_BYTES + XT_BYTES];
-  char* Ks = smem;
-  char* Vs = smem + DT_BYTES;
-  char* Kt = smem + 2 * DT_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
@@ -257,6 +253,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
   const float c2 = p.scale * 1.44269504088896340736f;
+  const uint32_t lds0 = lds_addr(smem);
+
+  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
+  const int kt_end = (min(q0 + 63, M - 1)) / 64;
+  const int n = kt_end - kt_begin + 1;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % DQ_NST) * 3 * IMG);
+    const int r0 = (kt_begin + t) * 64;
+    dma_tile64<false>(Kb, ld, r0, M, tid, st);
+    dma_tile64<true>(Kb, ld, r0, M, tid, st + IMG);
+    dma_tile64<false>(Vb, ld, r0, M, tid, st + 2 * IMG);
+  };
+#pragma unroll
+  for (int s = 0; s < DQ_NST - 1; ++s)
+    if (s < n) issue(s);
 
   const int q = qw0 + l15;
   const int qc = q < M ? q : M - 1;
@@ -274,52 +285,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
   for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
-  const int kt_end = (min(q0 + 63, M - 1)) / 64;
-  uint4 kr0, kr1, vr0, vr1;
-  tile_load(Kb, ld, kt_begin * 64, M, tid, kr0, kr1);
-  tile_load(Vb, ld, kt_begin * 64, M, tid, vr0, vr1);
-  for (int kt = kt_begin; kt <= kt_end; ++kt) {
-    tile_store_direct(Ks, tid, kr0, kr1);
-    tile_store_transposed(Kt, tid, kr0, kr1);
-    tile_store_direct(Vs, tid, vr0, vr1);
+  for (int t = 0; t < n; ++t) {
+    if (n - 1 - t >= 1) wait_vmcnt<6>();
+    else wait_vmcnt<0>();
     __syncthreads();
-    if (kt < kt_end) {
-      tile_load(Kb, ld, (kt + 1) * 64, M, tid, kr0, kr1);
-      tile_load(Vb, ld, (kt + 1) * 64, M, tid, vr0, vr1);
-    }
-    const int key0 = kt * 64;
-    if (key0 <= qw0 + 15) {
-      f32x4_t st[4], dp[4];
+    if (t + DQ_NST - 1 < n) issue(t + DQ_NST - 1);
+    const char* Ks = smem + (t % DQ_NST) * 3 * IMG;
+    const char* Kt = Ks + IMG;
+    const char* Vs = Ks + 2 * IMG;
+    const int key0 = (kt_begin + t) * 64;
+    if (key0 > qw0 + 15) continue;
+    f32x4_t st[4], dp[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) { st[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[f] = st[f]; }
+    for (int f = 0; f < 4; ++f) { st[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[f] = st[f]; }
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          st[f] = mfma16(frag_direct(Ks, f, l15, g, ds), qf[ds], st[f]);
-          dp[f] = mfma16(frag_direct(Vs, f, l15, g, ds), dof[ds], dp[f]);
+      for (int f = 0; f < 4; ++f) {
+        st[f] = mfma16(frag_direct(Ks, f, l15, g, ds), qf[ds], st[f]);
+        dp[f] = mfma16(frag_direct(Vs, f, l15, g, ds), dof[ds], dp[f]);
+      }
+    const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + 15 >= M);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pe = exp2f(fmaf(st[f][r], c2, -lse));
+        if (need_mask) {
+          int key = key0 + f * 16 + g * 4 + r;
+          bool ok = (key <= q) && (key >= seg) && (q < M);
+          pe = ok ? pe : 0.f;
         }
-      const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + 15 >= M);
+        st[f][r] = pe * (dp[f][r] - dsm);
+      }
+    uint4 dsb[2] = {pack_pair(st[0], st[1]), pack_pair(st[2], st[3])};
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pe = exp2f(fmaf(st[f][r], c2, -lse));
-          if (need_mask) {
-            int key = key0 + f * 16 + g * 4 + r;
-            bool ok = (key <= q) && (key >= seg) && (q < M);
-            pe = ok ? pe : 0.f;
-          }
-          st[f][r] = pe * (dp[f][r] - dsm);
-        }
-      uint4 dsb[2] = {pack_pair(st[0], st[1]), pack_pair(st[2], st[3])};
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd) dq[fd] = mfma16(frag_transposed(Kt, fd, l15, g, t), dsb[t], dq[fd]);
-    }
-    __syncthreads();
+      for (int fd = 0; fd < 4; ++fd) dq[fd] = mfma16(frag_tr(Kt, fd, l15, g, t2), dsb[t2], dq[fd]);
   }
   if (q < M) {
 #pragma unroll
@@ -335,15 +338,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 // dK / dV per query head. grid (ceil(M/64), nH); wave w owns keys k0+16w .. +15; fp32 partials
 // dkv_part[0|1][h][m][64] are summed over the heads of a KV group by attn_dkv_reduce_kernel.
+// Stage = Q D/T images + dO D/T images (32 KB) + lse2 / dsum / seg_start of the 64 query rows
+// (3 x 256 B, by 4-byte LDS-DMA), 2-stage ring, 9 DMAs per lane per tile.
+constexpr int DKV_NST = 2;
+constexpr int DKV_STAGE = 4 * IMG + 1024;
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * DT_BYTES + 2 * XT_BYTES + 3 * 256];
-  char* Qs = smem;
-  char* dOs = smem + DT_BYTES;
-  char* Qt = smem + 2 * DT_BYTES;
-  char* dOt = Qt + XT_BYTES;
-  float* lse_s = reinterpret_cast<float*>(dOt + XT_BYTES);
-  float* dsm_s = lse_s + 64;
-  int* seg_s = reinterpret_cast<int*>(dsm_s + 64);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, kvh = h / (p.nH / p.nKV);
@@ -354,6 +354,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
   const bf16_t* dOb = p.d_o + h * 64;
   const float c2 = p.scale * 1.44269504088896340736f;
+  const uint32_t lds0 = lds_addr(smem);
+
+  const int qt_begin = k0 / 64;
+  const int qt_end = (p.seg_end[min(k0 + 63, M - 1)] - 1) / 64;
+  const int n = qt_end - qt_begin + 1;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % DKV_NST) * DKV_STAGE);
+    const int r0 = (qt_begin + t) * 64;
+    dma_tile64<false>(Qb, ld, r0, M, tid, st);
+    dma_tile64<true>(Qb, ld, r0, M, tid, st + IMG);
+    dma_tile64<false>(dOb, ldo, r0, M, tid, st + 2 * IMG);
+    dma_tile64<true>(dOb, ldo, r0, M, tid, st + 3 * IMG);
+    // per-row scalars: wave 0 -> lse2, 1 -> dsum, 2 -> seg_start, 3 -> spare slot (keeps the DMA count uniform)
+    const int row = min(r0 + lane, M - 1);
+    const void* src = wv == 0 ? (const void*)(p.lse2 + (size_t)h * M + row)
+                    : wv == 1 ? (const void*)(p.dsum + (size_t)h * M + row)
+                              : (const void*)(p.seg_start + row);
+    glds4(src, __builtin_amdgcn_readfirstlane(st + 4 * IMG + (uint32_t)wv * 256u));
+  };
+  if (n > 0) issue(0);
 
   const int key = k0 + wave * 16 + l15;
   const int kc = key < M ? key : M - 1;
@@ -367,73 +388,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
   for (int fd = 0; fd < 4; ++fd) { dk[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[fd] = dk[fd]; }
 
-  const int qt_begin = k0 / 64;
-  const int qt_end = (p.seg_end[min(k0 + 63, M - 1)] - 1) / 64;
-  uint4 qr0, qr1, gr0, gr1;
-  tile_load(Qb, ld, qt_begin * 64, M, tid, qr0, qr1);
-  tile_load(dOb, ldo, qt_begin * 64, M, tid, gr0, gr1);
-  for (int qt = qt_begin; qt <= qt_end; ++qt) {
-    const int qbase = qt * 64;
-    tile_store_direct(Qs, tid, qr0, qr1);
-    tile_store_transposed(Qt, tid, qr0, qr1);
-    tile_store_direct(dOs, tid, gr0, gr1);
-    tile_store_transposed(dOt, tid, gr0, gr1);
-    if (tid < 64) {
-      int qq = qbase + tid;
-      int qcl = qq < M ? qq : M - 1;
-      lse_s[tid] = p.lse2[(size_t)h * M + qcl];
-      dsm_s[tid] = p.dsum[(size_t)h * M + qcl];
-      seg_s[tid] = qq < M ? p.seg_start[qcl] : 0x7fffffff;  // rows past M never validate
-    }
+  for (int t = 0; t < n; ++t) {
+    wait_vmcnt<0>();
     __syncthreads();
-    if (qt < qt_end) {
-      tile_load(Qb, ld, (qt + 1) * 64, M, tid, qr0, qr1);
-      tile_load(dOb, ldo, (qt + 1) * 64, M, tid, gr0, gr1);
-    }
-    if (qbase + 63 >= k0 + wave * 16) {  // some query of the tile can see this wave's keys
-      f32x4_t s[4], dp[4];
+    if (t + 1 < n) issue(t + 1);
+    const char* Qs = smem + (t % DKV_NST) * DKV_STAGE;
+    const char* Qt = Qs + IMG;
+    const char* dOs = Qs + 2 * IMG;
+    const char* dOt = Qs + 3 * IMG;
+    const float* lse_s = reinterpret_cast<const float*>(Qs + 4 * IMG);
+    const float* dsm_s = lse_s + 64;
+    const int* seg_s = reinterpret_cast<const int*>(lse_s + 128);
+    const int qbase = (qt_begin + t) * 64;
+    const int kw0 = k0 + wave * 16;
+    if (qbase + 63 < kw0) continue;  // no query of the tile can see this wave's keys
+    f32x4_t s[4], dp[4];
 #pragma unroll
-      for (int jq = 0; jq < 4; ++jq) { s[jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[jq] = s[jq]; }
+    for (int jq = 0; jq < 4; ++jq) { s[jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[jq] = s[jq]; }
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds)
-#pragma unroll
-        for (int jq = 0; jq < 4; ++jq) {
-          s[jq] = mfma16(frag_direct(Qs, jq, l15, g, ds), kf[ds], s[jq]);
-          dp[jq] = mfma16(frag_direct(dOs, jq, l15, g, ds), vf[ds], dp[jq]);
-        }
-      // lane holds (q = qbase + jq*16 + 4g + r, key); mask only on diagonal / segment-boundary / tail tiles
-      const int kw0 = k0 + wave * 16;
-      const bool need_mask = (kw0 + 15 > qbase) || (kw0 < seg_s[63]) || (qbase + 63 >= M);
+    for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
       for (int jq = 0; jq < 4; ++jq) {
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + jq * 16 + g * 4);
-        const float4 d4 = *reinterpret_cast<const float4*>(dsm_s + jq * 16 + g * 4);
-        const int4 s4 = *reinterpret_cast<const int4*>(seg_s + jq * 16 + g * 4);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-        const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pe = exp2f(fmaf(s[jq][r], c2, -lv[r]));
-          if (need_mask) {
-            int qq = qbase + jq * 16 + g * 4 + r;
-            bool ok = (key <= qq) && (key >= sv[r]);
-            pe = ok ? pe : 0.f;
-          }
-          s[jq][r] = pe;
-          dp[jq][r] = pe * (dp[jq][r] - dvv[r]);
-        }
+        s[jq] = mfma16(frag_direct(Qs, jq, l15, g, ds), kf[ds], s[jq]);
+        dp[jq] = mfma16(frag_direct(dOs, jq, l15, g, ds), vf[ds], dp[jq]);
       }
-      uint4 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
-      uint4 dsb[2] = {pack_pair(dp[0], dp[1]), pack_pair(dp[2], dp[3])};
+    // lane holds (q = qbase + jq*16 + 4g + r, key); mask only on diagonal / segment-boundary / tail tiles
+    const bool need_mask = (kw0 + 15 > qbase) || (kw0 < seg_s[63]) || (qbase + 63 >= M);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int jq = 0; jq < 4; ++jq) {
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + jq * 16 + g * 4);
+      const float4 d4 = *reinterpret_cast<const float4*>(dsm_s + jq * 16 + g * 4);
+      const int4 s4 = *reinterpret_cast<const int4*>(seg_s + jq * 16 + g * 4);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+      const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) {
-          dv[fd] = mfma16(frag_transposed(dOt, fd, l15, g, t), pb[t], dv[fd]);
-          dk[fd] = mfma16(frag_transposed(Qt, fd, l15, g, t), dsb[t], dk[fd]);
+      for (int r = 0; r < 4; ++r) {
+        float pe = exp2f(fmaf(s[jq][r], c2, -lv[r]));
+        if (need_mask) {
+          int qq = qbase + jq * 16 + g * 4 + r;
+          bool ok = (key <= qq) && (key >= sv[r]) && (qq < M);
+          pe = ok ? pe : 0.f;
         }
+        s[jq][r] = pe;
+        dp[jq][r] = pe * (dp[jq][r] - dvv[r]);
+      }
     }
-    __syncthreads();
+    uint4 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+    uint4 dsb[2] = {pack_pair(dp[0], dp[1]), pack_pair(dp[2], dp[3])};
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        dv[fd] = mfma16(frag_tr(dOt, fd, l15, g, t2), pb[t2], dv[fd]);
+        dk[fd] = mfma16(frag_tr(Qt, fd, l15, g, t2), dsb[t2], dk[fd]);
+      }
   }
   if (key < M) {
     float* dkp = p.dkv_part + ((size_t)h * M + key) * 64;
@@ -475,13 +483,28 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p) {
 
 namespace slam {
 
+static int set_lds_attrs() {
+  static bool done = false;
+  if (done) return 0;
+  hipError_t e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NST * 2 * IMG);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NST * 3 * IMG);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NST * DKV_STAGE);
+  if (e != hipSuccess) return (int)e;
+  done = true;
+  return 0;
+}
+
 int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, int M, int nH, int nKV,
              int head_dim, hipStream_t st) {
   if (head_dim != 64 || nH % nKV) return -1;
   AttnArgs a{};
   a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
-  attn_fwd_kernel<<<dim3((M + 127) / 128, nH), 256, 0, st>>>(a);
+  if (int e = set_lds_attrs()) return e;
+  attn_fwd_kernel<<<dim3((M + 127) / 128, nH), 256, FWD_NST * 2 * IMG, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -496,9 +519,10 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
   a.lse2 = const_cast<float*>(lse2); a.dsum = dsum; a.dkv_part = dkv_part;
   a.seg_start = seg_start; a.seg_end = seg_end;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
+  if (int e = set_lds_attrs()) return e;
   attn_dsum_kernel<<<(unsigned)(((size_t)M * nH + 255) / 256), 256, 0, st>>>(a);
-  attn_bwd_dq_kernel<<<dim3((M + 63) / 64, nH), 256, 0, st>>>(a);
-  attn_bwd_dkv_kernel<<<dim3((M + 63) / 64, nH), 256, 0, st>>>(a);
+  attn_bwd_dq_kernel<<<dim3((M + 63) / 64, nH), 256, DQ_NST * 3 * IMG, st>>>(a);
+  attn_bwd_dkv_kernel<<<dim3((M + 63) / 64, nH), 256, DKV_NST * DKV_STAGE, st>>>(a);
   size_t total = (size_t)2 * M * nKV * 16;
   attn_dkv_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
   return (int)hipGetLastError();

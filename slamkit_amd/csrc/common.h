@@ -66,6 +66,52 @@ SLAM_DEVICE f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
 SLAM_DEVICE int lds_swz_key(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
 SLAM_DEVICE int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ lds_swz_key(row)) << 4); }
 
+// ---- LDS-DMA + transpose-read primitives (gfx950) -------------------------------------------------
+// global_load_lds_dwordx4: 64 lanes x 16 B (each lane its own source address) land in LDS at
+// M0 + lane*16. Issued from inline asm so hipcc's waitcnt insertion does not see it (it would drain
+// it with vmcnt(0) before every ds_read); callers count completion with s_waitcnt vmcnt(N).
+SLAM_DEVICE void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+// 4-byte variant: 64 lanes x 4 B -> LDS at M0 + lane*4
+SLAM_DEVICE void glds4(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+SLAM_DEVICE void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+SLAM_DEVICE uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+// ds_read_b64_tr_b16: within each 16-lane group, out[lane c][j] = in[lane 4j + (c>>2)][c&3] where
+// in[lane i] are the 4 contiguous bf16 at lane i's address (measured: tools/probes/tr_probe.hip).
+// With lane i pointing at X[k0 + (i>>2)][c0 + 4(i&3)..+3], lane c receives X[k0..k0+3][c0 + c]:
+// four consecutive contraction rows of one column = half an MFMA operand.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+SLAM_DEVICE uint2 lds_tr_read(const char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
 #define HIP_CHECK_RET(expr)                                     \
   do {                                                          \
     hipError_t _e = (expr);                                     \

@@ -111,19 +111,6 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t 
 //      LDS at M0 + lane*16; issued from asm so the compiler's waitcnt insertion does not see it
 //      (we count it ourselves with s_waitcnt vmcnt(N)). Rows past the end are clamped: their
 //      products only reach output rows that are never stored. ---------------------------------
-SLAM_DEVICE void glds16(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-
 SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0, int tid, uint32_t tile_lds) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -146,7 +133,6 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
 //      in[lane 4j + (c>>2)][c&3], every lane supplying the address of 4 contiguous bf16).
 //      32-byte row-blocks are XOR-swizzled with key(kc) = (kc&3) | ((kc>>3)&1)<<2 so the 8 kc rows
 //      a 32-lane group touches fall into 8 distinct 32-B windows of the 256-B bank row. ----------
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 SLAM_DEVICE int tr_key(int kc) { return (kc & 3) | (((kc >> 3) & 1) << 2); }
 
 SLAM_DEVICE void glds_tile_tr(const bf16_t* G, int ld, int k0, int row0, int tid, uint32_t tile_lds) {
@@ -160,19 +146,6 @@ SLAM_DEVICE void glds_tile_tr(const bf16_t* G, int ld, int k0, int row0, int tid
     uint32_t dst = __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u);
     glds16(src, dst);
   }
-}
-
-SLAM_DEVICE uint2 lds_tr_read(const char* p) {
-  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-  return __builtin_bit_cast(uint2, v);
-}
-
-template <int N>
-SLAM_DEVICE void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
 template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */>
@@ -259,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   if constexpr (GLDS) {
     constexpr int D = NSTAGE - 1;  // tiles in flight ahead of the one being computed
     constexpr bool TR = TA && TB;  // both operands stored [contraction][rows]: DMA + transpose reads
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t lds0 = lds_addr(smem);
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
       const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
