@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[j], mx);
-      const float alpha = exp2f((mrun[j] - mnew) * c2);
+      const float alpha = fast_exp2((mrun[j] - mnew) * c2);
       mrun[j] = mnew;
       const float mc = mnew * c2;
       float ps = 0.f;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           // masked entries are NEG_BIG: exp2 underflows to 0 unless the whole row is still masked
           // (mnew == NEG_BIG), which the explicit select handles
-          float e = exp2f(fmaf(st[f][j][r], c2, -mc));
+          float e = fast_exp2(fmaf(st[f][j][r], c2, -mc));
           if (need_mask) e = (st[f][j][r] <= 0.5f * NEG_BIG) ? 0.f : e;
           st[f][j][r] = e;
           ps += e;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pe = exp2f(fmaf(st[f][r], c2, -lse));
+        float pe = fast_exp2(fmaf(st[f][r], c2, -lse));
         if (need_mask) {
           int key = key0 + f * 16 + g * 4 + r;
           bool ok = (key <= q) && (key >= seg) && (q < M);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
       const int sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pe = exp2f(fmaf(s[jq][r], c2, -lv[r]));
+        float pe = fast_exp2(fmaf(s[jq][r], c2, -lv[r]));
         if (need_mask) {
           int qq = qbase + jq * 16 + g * 4 + r;
           bool ok = (key <= qq) && (key >= sv[r]) && (qq < M);

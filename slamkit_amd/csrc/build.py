@@ -13,7 +13,9 @@ LIB_DIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIB_DIR, "libslam_engine.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "slam_engine.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it the
+# attention kernels spend 256 v_accvgpr_read/write per K/V tile moving the online-softmax state around.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():

@@ -35,6 +35,9 @@ SLAM_DEVICE uint4 pack_bf16x8(const float* f) {
   return v;
 }
 
+// raw v_exp_f32 (2^x): no denormal-range fix-up code (arguments here are <= 0 or moderate)
+SLAM_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 SLAM_DEVICE float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
