@@ -85,6 +85,20 @@ SLAM_DEVICE void glds16(const void* gsrc, uint32_t lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// same, source = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: the
+// per-lane offsets are tile-invariant, so a K-loop only advances the scalar base (no VALU).
+SLAM_DEVICE void glds16_sv(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 // 4-byte variant: 64 lanes x 4 B -> LDS at M0 + lane*4
 SLAM_DEVICE void glds4(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;

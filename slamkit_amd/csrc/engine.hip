@@ -59,7 +59,7 @@ struct SlamEngine {
   std::vector<LayerAct> la;
   bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
-  int *seg_s, *seg_e;
+  int *seg_s, *seg_e, *attn_plan_buf;
 
   // last forward
   int B = 0, T = 0;
@@ -138,6 +138,7 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->sinb = c.take<float>(M * (d.head_dim / 2));
   e->seg_s = c.take<int>(M);
   e->seg_e = c.take<int>(M);
+  e->attn_plan_buf = c.take<int>(attn_plan_ints((int)M));
   e->gemm_ws = c.take<float>(max_gemm_ws(e, (int)M) / sizeof(float));
   size_t part = (size_t)rmsnorm_bwd_blocks((int)M) * H;
   size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
@@ -300,6 +301,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     h->cur_seg_s = h->seg_s;
     h->cur_seg_e = h->seg_e;
   }
+  CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, h->attn_plan_buf, st));
   CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
   CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
   for (int l = 0; l < L; ++l) {
@@ -308,7 +310,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
     CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
     CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 0, st));
-    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, M, nH, nKV, d.head_dim, st));
+    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
     CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
     CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
@@ -373,7 +375,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     // attention
     CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, M, nH, nKV,
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, M, nH, nKV,
                 d.head_dim, st));
     CK(rope_apply(h->dqkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 1, st));
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, G + o.bqkv, 1, h->part_ws, st));
@@ -469,17 +471,20 @@ int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s
 }
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
                      slam_stream_t s) {
-  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, M, nH, nKV, 64, (hipStream_t)s);
+  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, M, nH, nKV, 64, (hipStream_t)s);
 }
 size_t slam_op_attn_bwd_workspace(int M, int nH) {
-  return attn_bwd_workspace_bytes(M, nH) + (size_t)M * nH * sizeof(float);
+  return attn_bwd_workspace_bytes(M, nH) + (size_t)M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
 }
 int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
                      const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, slam_stream_t s) {
   float* dsum = ws;
   float* part = ws + (size_t)M * nH;
+  int* plan = reinterpret_cast<int*>(part + attn_bwd_workspace_bytes(M, nH) / sizeof(float));
+  int r = attn_plan(seg_start, seg_end, M, plan, (hipStream_t)s);
+  if (r) return r;
   return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, dsum, (bf16_t*)dqkv, part, seg_start,
-                  seg_end, M, nH, nKV, 64, (hipStream_t)s);
+                  seg_end, plan, M, nH, nKV, 64, (hipStream_t)s);
 }
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
                           float* scratch2, int B, int T, int V, slam_stream_t s) {

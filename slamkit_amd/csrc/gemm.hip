@@ -111,8 +111,9 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t 
 //      LDS at M0 + lane*16; issued from asm so the compiler's waitcnt insertion does not see it
 //      (we count it ourselves with s_waitcnt vmcnt(N)). Rows past the end are clamped: their
 //      products only reach output rows that are never stored. ---------------------------------
-SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0, int tid, uint32_t tile_lds) {
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Per-lane byte offsets (tile-invariant) of the 4 chunks a lane moves; the K-loop only advances the
+// wave-uniform base pointer G + k0.
+SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* voff) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int P = i * 256 + tid;
@@ -120,10 +121,14 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
     int c = cs ^ lds_swz_key(row);
     int gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
-    const bf16_t* src = G + (size_t)gr * ld + k0 + c * 8;
-    uint32_t dst = __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u);
-    glds16(src, dst);
+    voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
+}
+SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const uint32_t* voff, int wave,
+                           uint32_t tile_lds) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    glds16_sv(Gk, voff[i], __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u));
 }
 
 // ---- transposed operands through LDS-DMA + hardware transpose reads (wgrad). The operand is
@@ -135,16 +140,13 @@ SLAM_DEVICE void glds_tile(const bf16_t* G, int ld, int nrows, int row0, int k0,
 //      a 32-lane group touches fall into 8 distinct 32-B windows of the 256-B bank row. ----------
 SLAM_DEVICE int tr_key(int kc) { return (kc & 3) | (((kc >> 3) & 1) << 2); }
 
-SLAM_DEVICE void glds_tile_tr(const bf16_t* G, int ld, int k0, int row0, int tid, uint32_t tile_lds) {
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int P = i * 256 + tid;
     int kc = P >> 4, cs = P & 15;
     int c = cs ^ (tr_key(kc) << 1);
-    const bf16_t* src = G + (size_t)(k0 + kc) * ld + row0 + c * 8;
-    uint32_t dst = __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u);
-    glds16(src, dst);
+    voff[i] = (uint32_t)(((size_t)kc * ld + row0 + c * 8) * sizeof(bf16_t));
   }
 }
 
@@ -233,16 +235,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr int D = NSTAGE - 1;  // tiles in flight ahead of the one being computed
     constexpr bool TR = TA && TB;  // both operands stored [contraction][rows]: DMA + transpose reads
     const uint32_t lds0 = lds_addr(smem);
+    uint32_t voa[4], vob[4];
+    if constexpr (TR) {
+      glds_offsets_tr(p.lda, row0, tid, voa);
+      glds_offsets_tr(p.ldb, col0, tid, vob);
+    } else {
+      glds_offsets(p.lda, p.R, row0, tid, voa);
+      glds_offsets(p.ldb, p.Cn, col0, tid, vob);
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
       const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
-      if constexpr (TR) {
-        glds_tile_tr(p.A, p.lda, k0, row0, tid, st);
-        glds_tile_tr(p.B, p.ldb, k0, col0, tid, st + TILE_BYTES);
-      } else {
-        glds_tile(p.A, p.lda, p.R, row0, k0, tid, st);
-        glds_tile(p.B, p.ldb, p.Cn, col0, k0, tid, st + TILE_BYTES);
-      }
+      // wave-uniform bases: direct operands advance along the contiguous contraction dim, transposed
+      // operands by whole rows
+      const bf16_t* ga = TR ? p.A + (size_t)k0 * p.lda : p.A + k0;
+      const bf16_t* gb = TR ? p.B + (size_t)k0 * p.ldb : p.B + k0;
+      glds_tile(ga, voa, wv, st);
+      glds_tile(gb, vob, wv, st + TILE_BYTES);
     };
 #pragma unroll
     for (int s = 0; s < D; ++s)

@@ -22,12 +22,14 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
             float* ws, hipStream_t st);
 
 // attention.hip
-int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, int M, int nH, int nKV, int head_dim,
-             hipStream_t st);
+size_t attn_plan_ints(int M);
+int attn_plan(const int* seg_start, const int* seg_end, int M, int* plan, hipStream_t st);
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH, int nKV,
+             int head_dim, hipStream_t st);
 size_t attn_bwd_workspace_bytes(int M, int nH);
 int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum, bf16_t* dqkv,
-             float* dkv_part, const int* seg_start, const int* seg_end, int M, int nH, int nKV, int head_dim,
-             hipStream_t st);
+             float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, int M, int nH, int nKV,
+             int head_dim, hipStream_t st);
 
 // elementwise.hip
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
