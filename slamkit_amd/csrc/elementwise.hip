@@ -547,7 +547,7 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
   LAUNCH_RET();
 }
 
-int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 256 ? 256 : (b < 1 ? 1 : b); }  // 1 block/CU
+int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {

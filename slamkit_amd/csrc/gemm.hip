@@ -113,10 +113,11 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t 
 //      products only reach output rows that are never stored. ---------------------------------
 // Per-lane byte offsets (tile-invariant) of the 4 chunks a lane moves; the K-loop only advances the
 // wave-uniform base pointer G + k0.
+template <int THREADS>
 SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* voff) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int P = i * 256 + tid;
+  for (int i = 0; i < 1024 / THREADS; ++i) {
+    int P = i * THREADS + tid;
     int row = P >> 3, cs = P & 7;
     int c = cs ^ lds_swz_key(row);
     int gr = row0 + row;
@@ -124,11 +125,12 @@ SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* vo
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
+template <int THREADS>
 SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const uint32_t* voff, int wave,
                            uint32_t tile_lds) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    glds16_sv(Gk, voff[i], __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * 256 + wave * 64) * 16u));
+  for (int i = 0; i < 1024 / THREADS; ++i)
+    glds16_sv(Gk, voff[i], __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * THREADS + wave * 64) * 16u));
 }
 
 // ---- transposed operands through LDS-DMA + hardware transpose reads (wgrad). The operand is
@@ -140,23 +142,29 @@ SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const 
 //      a 32-lane group touches fall into 8 distinct 32-B windows of the 256-B bank row. ----------
 SLAM_DEVICE int tr_key(int kc) { return (kc & 3) | (((kc >> 3) & 1) << 2); }
 
+template <int THREADS>
 SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int P = i * 256 + tid;
+  for (int i = 0; i < 1024 / THREADS; ++i) {
+    int P = i * THREADS + tid;
     int kc = P >> 4, cs = P & 15;
     int c = cs ^ (tr_key(kc) << 1);
     voff[i] = (uint32_t)(((size_t)kc * ld + row0 + c * 8) * sizeof(bf16_t));
   }
 }
 
-template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+// WAVES = 4: 2x2 waves of 64x64, 2 blocks/CU; WAVES = 8: 2x4 waves of 64x32, one block per CU with a
+// deeper DMA ring (same 2 waves per SIMD, more latency budget per tile).
+template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool GLDS = NSTAGE > 0;
+  constexpr int THREADS = WAVES * 64;
+  constexpr int NF = WAVES == 4 ? 4 : 2;  // 16-column fragments per wave
+  static_assert(WAVES == 4 || (WAVES == 8 && NSTAGE > 0), "8-wave blocks exist for the DMA ring only");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WAVES == 4 ? (wave >> 1) : (wave >> 2), wn = WAVES == 4 ? (wave & 1) : (wave & 3);
   const int l15 = lane & 15, g = lane >> 4;
 
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -174,16 +182,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int kend = min(p.Kc, kbeg + p.kc_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][NF];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // swizzle key of row (w*64 + f*16 + l15) = ((l15>>1) ^ (w*4 + f)) & 7 = s0 ^ f
-  const int s0a = ((l15 >> 1) ^ (wn * 4)) & 7;
+  const int s0a = ((l15 >> 1) ^ (wn * NF)) & 7;
   const int s0b = ((l15 >> 1) ^ (wm * 4)) & 7;
-  const int a_base = (wn * 64 + l15) * 128;  // a-operand = column (B) tile
+  const int a_base = (wn * NF * 16 + l15) * 128;  // a-operand = column (B) tile
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
   auto compute = [&](int s) {
@@ -192,16 +200,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
-      uint4 af[4], bf[4];
+      uint4 af[NF], bf[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < NF; ++f)
         af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
         bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
-      }
 #pragma unroll
       for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+        for (int fn = 0; fn < NF; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
     }
   };
 
@@ -214,20 +223,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const char* Bt = At + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 af[4], bf[4];
+      uint4 af[NF], bf[4];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const char* pa = Bt + tr_lane + kk * 32 * 256 + (((wn * NF + f) ^ trk) << 5);
+        uint2 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * 256);
+        af[f] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+      }
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const char* pa = Bt + tr_lane + kk * 32 * 256 + (((wn * 4 + f) ^ trk) << 5);
         const char* pb = At + tr_lane + kk * 32 * 256 + (((wm * 4 + f) ^ trk) << 5);
-        uint2 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * 256);
         uint2 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * 256);
-        af[f] = make_uint4(a0.x, a0.y, a1.x, a1.y);
         bf[f] = make_uint4(b0.x, b0.y, b1.x, b1.y);
       }
 #pragma unroll
       for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+        for (int fn = 0; fn < NF; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
     }
   };
 
@@ -237,12 +249,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const uint32_t lds0 = lds_addr(smem);
     uint32_t voa[4], vob[4];
     if constexpr (TR) {
-      glds_offsets_tr(p.lda, row0, tid, voa);
-      glds_offsets_tr(p.ldb, col0, tid, vob);
+      glds_offsets_tr<THREADS>(p.lda, row0, tid, voa);
+      glds_offsets_tr<THREADS>(p.ldb, col0, tid, vob);
     } else {
-      glds_offsets(p.lda, p.R, row0, tid, voa);
-      glds_offsets(p.ldb, p.Cn, col0, tid, vob);
+      glds_offsets<THREADS>(p.lda, p.R, row0, tid, voa);
+      glds_offsets<THREADS>(p.ldb, p.Cn, col0, tid, vob);
     }
+    constexpr int PT = 2 * (1024 / THREADS);  // DMAs per lane per tile
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       // operands by whole rows
       const bf16_t* ga = TR ? p.A + (size_t)k0 * p.lda : p.A + k0;
       const bf16_t* gb = TR ? p.B + (size_t)k0 * p.ldb : p.B + k0;
-      glds_tile(ga, voa, wv, st);
-      glds_tile(gb, vob, wv, st + TILE_BYTES);
+      glds_tile<THREADS>(ga, voa, wv, st);
+      glds_tile<THREADS>(gb, vob, wv, st + TILE_BYTES);
     };
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -260,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
       // tile t has landed once at most min(D-1, nk-1-t) later tiles (8 DMAs each) are outstanding
       const int rem = min(D - 1, nk - 1 - t);
-      if (D >= 3 && rem >= 2) wait_vmcnt<16>();
-      else if (D >= 2 && rem == 1) wait_vmcnt<8>();
+      if (D >= 3 && rem >= 2) wait_vmcnt<2 * PT>();
+      else if (D >= 2 && rem == 1) wait_vmcnt<PT>();
       else wait_vmcnt<0>();
       __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
       if (t + D < nk) issue(t + D);
@@ -314,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   uint2 bb[4];
   if (!F32OUT && p.bias) {
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      int n = col0 + wn * 64 + fn * 16 + g * 4;
+    for (int fn = 0; fn < NF; ++fn) {
+      int n = col0 + wn * NF * 16 + fn * 16 + g * 4;
       bb[fn] = *reinterpret_cast<const uint2*>(p.bias + (n < p.Cn ? n : 0));
     }
   }
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     if constexpr (F32OUT) {
       float* Cf = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.R * p.ldc;
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) {
-        const int n = col0 + wn * 64 + fn * 16 + g * 4;
+      for (int fn = 0; fn < NF; ++fn) {
+        const int n = col0 + wn * NF * 16 + fn * 16 + g * 4;
         f32x4_t v = acc[fm][fn];
         if (mok && n < p.Cn) *reinterpret_cast<float4*>(Cf + rowoff + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -336,14 +349,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       uint2 rr[4];
       if (p.resid) {
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn) {
-          int n = col0 + wn * 64 + fn * 16 + g * 4;
+        for (int fn = 0; fn < NF; ++fn) {
+          int n = col0 + wn * NF * 16 + fn * 16 + g * 4;
           rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + (n < p.Cn ? n : 0));
         }
       }
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) {
-        const int n = col0 + wn * 64 + fn * 16 + g * 4;
+      for (int fn = 0; fn < NF; ++fn) {
+        const int n = col0 + wn * NF * 16 + fn * 16 + g * 4;
         f32x4_t v = acc[fm][fn];
         if (p.bias) {
           v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
@@ -375,18 +388,18 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
-template <bool TA, bool TB, bool F32OUT, int NSTAGE>
+template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4>
 int launch(const GemmArgs& a, int splits, hipStream_t st) {
   constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, NSTAGE><<<grid, 256, lds, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES><<<grid, WAVES * 64, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -418,6 +431,8 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
     case 2: return launch<false, false, false, 2>(a, 1, st);
     case 3: return launch<false, false, false, 3>(a, 1, st);
     case 4: return launch<false, false, false, 4>(a, 1, st);
+    case 83: return launch<false, false, false, 3, 8>(a, 1, st);
+    case 84: return launch<false, false, false, 4, 8>(a, 1, st);
     default: return launch<false, false, false, 0>(a, 1, st);
   }
 }
