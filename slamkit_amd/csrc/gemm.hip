@@ -375,6 +375,101 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// ---- experimental: same 128x128x64 DMA ring, 32x32x16 MFMA (2x2 fragments of 32x32 per wave) ------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+SLAM_DEVICE f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__global__ __launch_bounds__(256, 2) void gemm_nt32_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NSTAGE = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hb = lane >> 5;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int row0 = (nid / p.tiles_c) * BM, col0 = (nid % p.tiles_c) * BN;
+  const int nk = (p.Kc + BK - 1) / BK;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // row = w*64 + f*32 + l31: key8 = ((l31>>1) ^ (w*4 + f*2 + (l31>>4))) & 7
+  const int s0a = ((l31 >> 1) ^ (wn * 4) ^ (l31 >> 4)) & 7, s0b = ((l31 >> 1) ^ (wm * 4) ^ (l31 >> 4)) & 7;
+  const int a_base = (wn * 64 + l31) * 128, b_base = (wm * 64 + l31) * 128;
+  auto compute = [&](int s) {
+    const char* At = smem + s * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = hb + 2 * ks;
+      uint4 af[2], bf[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 32 * 128 + ((ch ^ s0a ^ (f * 2)) << 4));
+        bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 32 * 128 + ((ch ^ s0b ^ (f * 2)) << 4));
+      }
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) acc[fm][fn] = mfma32(af[fn], bf[fm], acc[fm][fn]);
+    }
+  };
+  const uint32_t lds0 = lds_addr(smem);
+  uint32_t voa[4], vob[4];
+  glds_offsets<256>(p.lda, p.R, row0, tid, voa);
+  glds_offsets<256>(p.ldb, p.Cn, col0, tid, vob);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
+    glds_tile<256>(p.A + t * BK, voa, wv, st);
+    glds_tile<256>(p.B + t * BK, vob, wv, st + TILE_BYTES);
+  };
+  if (nk > 0) issue(0);
+  for (int t = 0; t < nk; ++t) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (t + 1 < nk) issue(t + 1);
+    compute(t % NSTAGE);
+  }
+  // D[i = n][j = m]: lane holds m = l31 (+32 fm), n = 8*(r>>2) + 4*hb + (r&3) (+32 fn)
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+    const int m = row0 + wm * 64 + fm * 32 + l31;
+    const bool mok = m < p.R;
+    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = col0 + wn * 64 + fn * 32 + 8 * q + 4 * hb;
+        float v0 = acc[fm][fn][4 * q], v1 = acc[fm][fn][4 * q + 1], v2 = acc[fm][fn][4 * q + 2], v3 = acc[fm][fn][4 * q + 3];
+        if (p.bias) {
+          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + n);
+          v0 += __uint_as_float(bb.x << 16); v1 += __uint_as_float(bb.x & 0xffff0000u);
+          v2 += __uint_as_float(bb.y << 16); v3 += __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (p.resid) {
+          uint2 rr = *reinterpret_cast<const uint2*>(p.resid + rowoff + n);
+          v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
+          v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v0, v1);
+        o.y = pack_bf16x2(v2, v3);
+        if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
+      }
+  }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
                                      int splits, int accumulate) {
@@ -431,6 +526,17 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
     case 2: return launch<false, false, false, 2>(a, 1, st);
     case 3: return launch<false, false, false, 3>(a, 1, st);
     case 4: return launch<false, false, false, 4>(a, 1, st);
+    case 32: {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+      }
+      gemm_nt32_kernel<<<a.tiles_r * a.tiles_c, 256, 2 * STAGE_BYTES, st>>>(a);
+      return (int)hipGetLastError();
+    }
     case 83: return launch<false, false, false, 3, 8>(a, 1, st);
     case 84: return launch<false, false, false, 4, 8>(a, 1, st);
     default: return launch<false, false, false, 0>(a, 1, st);
