@@ -50,7 +50,9 @@ typedef struct SlamModelDesc {
 
 typedef struct SlamTensorInfo {
   char name[64];      /* "embed", "layers.3.wqkv", "layers.3.bqkv", "layers.3.wo", "layers.3.ln1",
-                         "layers.3.ln2", "layers.3.wgu", "layers.3.wd", "norm" */
+                         "layers.3.ln2", "layers.3.wgu", "layers.3.wd", "norm".
+                         wqkv rows = q | k | v; wgu rows = blocks of 32 gate_proj rows followed by the
+                         matching 32 up_proj rows (row 64b+j = gate[32b+j], row 64b+32+j = up[32b+j]) */
   int64_t offset;     /* element offset in the flat parameter / gradient buffers */
   int64_t rows, cols; /* row-major [rows][cols] (cols = 1 for vectors) */
 } SlamTensorInfo;

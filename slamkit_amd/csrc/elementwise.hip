@@ -217,18 +217,21 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int
 }
 
 // ------------------------------------------------------------------------------------------
-// SwiGLU: gu [M][2I] (gate | up) -> act [M][I]
+// SwiGLU: gu [M][2I] -> act [M][I]. Column layout of gu: blocks of `blk` gate columns followed by the
+// matching `blk` up columns (blk = I: the plain gate|up halves; blk = 32: the engine's interleaved
+// layout that puts a gate/up pair into the same MFMA lane of the gate|up GEMM epilogue).
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
-                                                         size_t M, int I) {
+                                                         size_t M, int I, int blk) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   int nch = I >> 3;
   if (idx >= M * nch) return;
   size_t m = idx / nch;
   int c = idx % nch;
-  const bf16_t* row = gu + m * 2 * I;
+  const int a0 = c * 8;
+  const bf16_t* row = gu + m * 2 * I + (a0 / blk) * 2 * blk + (a0 % blk);
   float g[8], u[8], o[8];
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + c * 8), g);
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + I + c * 8), u);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row), g);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + blk), u);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
   *reinterpret_cast<uint4*>(act + m * I + c * 8) = pack_bf16x8(o);
@@ -236,16 +239,17 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
 
 // dgu (written in place over gu) from dact
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
-                                                         size_t M, int I) {
+                                                         size_t M, int I, int blk) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   int nch = I >> 3;
   if (idx >= M * nch) return;
   size_t m = idx / nch;
   int c = idx % nch;
-  bf16_t* row = gu + m * 2 * I;
+  const int a0 = c * 8;
+  bf16_t* row = gu + m * 2 * I + (a0 / blk) * 2 * blk + (a0 % blk);
   float g[8], u[8], d[8], dg[8], du[8];
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + c * 8), g);
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + I + c * 8), u);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row), g);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(row + blk), u);
   unpack_bf16x8(*reinterpret_cast<const uint4*>(dact + m * I + c * 8), d);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu
     du[j] = d[j] * silu;
     dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
   }
-  *reinterpret_cast<uint4*>(row + c * 8) = pack_bf16x8(dg);
-  *reinterpret_cast<uint4*>(row + I + c * 8) = pack_bf16x8(du);
+  *reinterpret_cast<uint4*>(row) = pack_bf16x8(dg);
+  *reinterpret_cast<uint4*>(row + blk) = pack_bf16x8(du);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -580,14 +584,14 @@ int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, cons
   LAUNCH_RET();
 }
 
-int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, hipStream_t st) {
-  if (I & 7) return -1;
-  swiglu_fwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, act, (size_t)M, I);
+int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, int blk, hipStream_t st) {
+  if ((I & 7) || (blk & 7) || I % blk) return -1;
+  swiglu_fwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, act, (size_t)M, I, blk);
   LAUNCH_RET();
 }
-int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, hipStream_t st) {
-  if (I & 7) return -1;
-  swiglu_bwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, dact, (size_t)M, I);
+int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, int blk, hipStream_t st) {
+  if ((I & 7) || (blk & 7) || I % blk) return -1;
+  swiglu_bwd_kernel<<<nblocks((size_t)M * (I / 8), 256), 256, 0, st>>>(gu, dact, (size_t)M, I, blk);
   LAUNCH_RET();
 }
 

@@ -18,6 +18,7 @@ using namespace slam;
 namespace {
 
 constexpr int VPAD = 512;
+constexpr int GU_BLK = 32;  // Wgu rows / gate|up columns come in blocks of 32 gate + 32 up
 
 struct LayerOff {
   int64_t ln1, wqkv, bqkv, wo, ln2, wgu, wd;
@@ -64,6 +65,7 @@ struct SlamEngine {
   // last forward
   int B = 0, T = 0;
   bool have_fwd = false, have_loss = false;
+  bool fuse_swiglu = false;
   const int64_t* last_ids = nullptr;
   const int* cur_seg_s = nullptr;
   const int* cur_seg_e = nullptr;
@@ -181,11 +183,12 @@ int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
   const SlamModelDesc& d = *desc;
   if (d.head_dim != 64 || d.n_heads <= 0 || d.n_kv_heads <= 0 || d.n_heads % d.n_kv_heads) return SLAM_EINVAL;
-  if (d.hidden % 8 || d.hidden > 2048 || d.intermediate % 8 || d.vocab <= 0 || d.vocab > VPAD) return SLAM_EINVAL;
+  if (d.hidden % 8 || d.hidden > 2048 || d.intermediate % GU_BLK || d.vocab <= 0 || d.vocab > VPAD) return SLAM_EINVAL;
   if (d.n_layers <= 0) return SLAM_EINVAL;
   SlamEngine* e = new SlamEngine();
   e->d = d;
   e->QKV = (d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
+  e->fuse_swiglu = (d.hidden % 64 == 0) && ((2 * d.intermediate) % 128 == 0);
   int64_t off = 0;
   e->off_embed = off;
   add_tensor(e, "embed", off, VPAD, d.hidden);
@@ -274,6 +277,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_glds")) { gemm_set_glds((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_dma")) { gemm_set_tn_dma((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
+  if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
 }
 
@@ -313,8 +317,12 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
     CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
-    CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
-    CK(swiglu_fwd(a.gu, a.act, M, I, st));
+    if (h->fuse_swiglu) {
+      CK(gemm_nt_swiglu(a.x2, P + o.wgu, a.gu, a.act, M, 2 * I, H, st));
+    } else {
+      CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
+      CK(swiglu_fwd(a.gu, a.act, M, I, GU_BLK, st));
+    }
     CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
   CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
@@ -368,7 +376,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     // MLP
     CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
     CK(dgrad(dh, o.wd, h->dact, H, I));
-    CK(swiglu_bwd(a.gu, h->dact, M, I, st));  // a.gu now holds d(gate|up)
+    CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, G + o.ln2, 1, h->part_ws, M, H, st));
@@ -464,10 +472,10 @@ int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, const int64_t
   return rope_apply((bf16_t*)qkv, ld, M, n_rot_heads, cs_ws, cs_ws + (size_t)M * 32, backward, (hipStream_t)s);
 }
 int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s) {
-  return swiglu_fwd((const bf16_t*)gu, (bf16_t*)act, M, I, (hipStream_t)s);
+  return swiglu_fwd((const bf16_t*)gu, (bf16_t*)act, M, I, I, (hipStream_t)s);
 }
 int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s) {
-  return swiglu_bwd((bf16_t*)gu, (const bf16_t*)dact, M, I, (hipStream_t)s);
+  return swiglu_bwd((bf16_t*)gu, (const bf16_t*)dact, M, I, I, (hipStream_t)s);
 }
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
                      slam_stream_t s) {

@@ -34,6 +34,7 @@ struct GemmArgs {
   void* C;
   const bf16_t* bias;
   const bf16_t* resid;
+  bf16_t* act;  // optional fused SwiGLU output [R][Cn/2] (4-wave kernel, 32-column gate/up blocks)
   int R, Cn, Kc;
   int lda, ldb, ldc;
   int kc_per_split;
@@ -371,6 +372,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
         o.y = pack_bf16x2(v[2], v[3]);
         if (mok && n < p.Cn) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
       }
+      if constexpr (WAVES == 4) {
+        // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up]; fragments fn and fn+2 of a lane
+        // hold gate and up of the same 4 activation columns
+        if (p.act && mok) {
+#pragma unroll
+          for (int fn = 0; fn < 2; ++fn) {
+            const int ac = (col0 + wn * 64) / 2 + fn * 16 + g * 4;
+            f32x4_t gt = acc[fm][fn], up = acc[fm][fn + 2];
+            float a0 = gt[0] / (1.f + __expf(-gt[0])) * up[0], a1 = gt[1] / (1.f + __expf(-gt[1])) * up[1];
+            float a2 = gt[2] / (1.f + __expf(-gt[2])) * up[2], a3 = gt[3] / (1.f + __expf(-gt[3])) * up[3];
+            uint2 o;
+            o.x = pack_bf16x2(a0, a1);
+            o.y = pack_bf16x2(a2, a3);
+            *reinterpret_cast<uint2*>(p.act + (size_t)m * (p.Cn / 2) + ac) = o;
+          }
+        }
+      }
     }
   }
 }
@@ -518,7 +536,7 @@ static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M,
             int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K & 7)) return -1;
-  GemmArgs a{X, W, Y, bias, resid, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
+  GemmArgs a{X, W, Y, bias, resid, nullptr, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (N + BN - 1) / BN};
   const bool dma_ok = (K % BK == 0) && (N % BN == 0);
   const int mode = dma_ok ? g_gemm_glds : 0;
@@ -543,11 +561,17 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   }
 }
 
+int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
+  if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
+  GemmArgs a{X, W, Y, nullptr, nullptr, act, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
+  return launch<false, false, false, 2>(a, 1, st);
+}
+
 // dX[M,K] = dY[M,N] W[N,K] (+resid[M,K]); contraction over N.
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st) {
   if (check_dims(M, K, N, N, K, K) || (N & 7)) return -1;
-  GemmArgs a{dY, W, dX, nullptr, resid, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
+  GemmArgs a{dY, W, dX, nullptr, resid, nullptr, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (K + BN - 1) / BN};
   return launch<false, true, false, 0>(a, 1, st);
 }
@@ -577,7 +601,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int splits = gemm_tn_splits(M, N, K);
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
-  GemmArgs a{dY, X, ws, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
+  GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
   const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
   int e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
   if (e) return e;

@@ -14,6 +14,8 @@ void gemm_set_tn_dma(int on);
 void gemm_set_tn_splits(int s);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);
+// same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
+int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st);
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);
@@ -41,8 +43,8 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
 int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st);
 int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, const float* sn, int backward,
                hipStream_t st);
-int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, hipStream_t st);
-int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, hipStream_t st);
+int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, int blk, hipStream_t st);
+int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, int blk, hipStream_t st);
 int embed_fwd(const int64_t* ids, const bf16_t* E, bf16_t* out, int M, int H, int V, hipStream_t st);
 int onehot(const int64_t* ids, bf16_t* oh, int M, int Vp, int V, int pad_id, hipStream_t st);
 int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,

@@ -178,21 +178,33 @@ class UnitLM(TokenLM):
             km[p + "self_attn.k_proj.bias"] = (o + nH * hd, (nKV * hd,))
             km[p + "self_attn.v_proj.bias"] = (o + (nH + nKV) * hd, (nKV * hd,))
             km[p + "self_attn.o_proj.weight"] = (t[q + "wo"].offset, (H, nH * hd))
-            o = t[q + "wgu"].offset
-            km[p + "mlp.gate_proj.weight"] = (o, (I, H))
-            km[p + "mlp.up_proj.weight"] = (o + I * H, (I, H))
+            o = t[q + "wgu"].offset  # rows interleaved in blocks of 32 gate / 32 up (slam_engine.h)
+            km[p + "mlp.gate_proj.weight"] = (o, (I, H), 0)
+            km[p + "mlp.up_proj.weight"] = (o, (I, H), 1)
             km[p + "mlp.down_proj.weight"] = (t[q + "wd"].offset, (H, I))
             km[p + "input_layernorm.weight"] = (t[q + "ln1"].offset, (H,))
             km[p + "post_attention_layernorm.weight"] = (t[q + "ln2"].offset, (H,))
         km["lm.model.norm.weight"] = (t["norm"].offset, (H,))
         self.key_map = km
 
-    def _view(self, flat: torch.Tensor, key: str) -> torch.Tensor:
-        off, shp = self.key_map[key]
+    def _view(self, flat: torch.Tensor, key: str, writable: bool = False) -> torch.Tensor:
+        """HF-named window of a flat engine buffer. gate_proj / up_proj live interleaved in 32-row blocks:
+        `writable` returns the strided [I/32, 32, H] view (copy_ from src.view(I//32, 32, H)), otherwise
+        an [I, H] copy."""
+        ent = self.key_map[key]
+        off, shp = ent[0], ent[1]
+        if len(ent) == 3:
+            I, H = shp
+            v = flat[off:off + 2 * I * H].view(I // 32, 2, 32, H)[:, ent[2]]
+            return v if writable else v.reshape(I, H)
         n = 1
         for s in shp:
             n *= s
         return flat[off:off + n].view(*shp)
+
+    def _assign(self, flat: torch.Tensor, key: str, src: torch.Tensor):
+        v = self._view(flat, key, writable=True)
+        v.copy_(src.to(device=flat.device, dtype=flat.dtype).reshape(v.shape))
 
     def _ensure_workspace(self, tokens: int):
         if tokens <= self._ws_tokens:
@@ -214,7 +226,7 @@ class UnitLM(TokenLM):
         g = torch.Generator(device=self.device).manual_seed(seed)
         self.flat_master.zero_()
         for k in self.key_map:
-            v = self._view(self.flat_master, k)
+            v = self._view(self.flat_master, k, writable=True)
             if k.endswith("norm.weight"):
                 v.fill_(1.0)
             elif k.endswith(".bias"):
@@ -222,7 +234,7 @@ class UnitLM(TokenLM):
             else:
                 v.normal_(0.0, std, generator=g)
         if self.config.pad_token_id is not None and self.config.pad_token_id >= 0:
-            self._view(self.flat_master, "lm.model.embed_tokens.weight")[self.config.pad_token_id].zero_()
+            self._view(self.flat_master, "lm.model.embed_tokens.weight", True)[self.config.pad_token_id].zero_()
         self.sync_params_from_master()
 
     def sync_params_from_master(self):
@@ -255,11 +267,11 @@ class UnitLM(TokenLM):
             raise KeyError(f"state_dict mismatch: missing={missing[:4]} unexpected={extra[:4]}")
         for k in self.key_map:
             if k in sd:
-                v = self._view(self.flat_master, k)
                 src = sd[k]
-                if k == "lm.model.embed_tokens.weight" and src.shape[0] > v.shape[0]:
-                    src = src[: v.shape[0]]  # resize_token_embeddings keeps the first V rows (unit_lm.py:102)
-                v.copy_(src.to(device=self.device, dtype=torch.float32))
+                nrow = self.key_map[k][1][0]
+                if k == "lm.model.embed_tokens.weight" and src.shape[0] > nrow:
+                    src = src[:nrow]  # resize_token_embeddings keeps the first V rows (unit_lm.py:102)
+                self._assign(self.flat_master, k, src)
         self.sync_params_from_master()
         return missing, extra
 
