@@ -375,8 +375,12 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     LayerAct& a = h->la[l];
     // MLP
     CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
-    CK(dgrad(dh, o.wd, h->dact, H, I));
-    CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
+    if (Pt && h->fuse_swiglu && (I % 128 == 0) && (H % 64 == 0)) {
+      CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
+    } else {
+      CK(dgrad(dh, o.wd, h->dact, H, I));
+      CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
+    }
     CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, G + o.ln2, 1, h->part_ws, M, H, st));

@@ -35,6 +35,7 @@ struct GemmArgs {
   const bf16_t* bias;
   const bf16_t* resid;
   bf16_t* act;  // optional fused SwiGLU output [R][Cn/2] (4-wave kernel, 32-column gate/up blocks)
+  bf16_t* gu;   // optional fused SwiGLU backward: the GEMM result is d(act) [R][Cn]; gu [R][2Cn] is rewritten in place with d(gate|up)
   int R, Cn, Kc;
   int lda, ldb, ldc;
   int kc_per_split;
@@ -346,6 +347,42 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
         f32x4_t v = acc[fm][fn];
         if (mok && n < p.Cn) *reinterpret_cast<float4*>(Cf + rowoff + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
+    } else if (p.gu) {
+      // fused SwiGLU backward: acc = d(act)[m][c..c+3]; gate at gu[m][(c/32)*64 + c%32], up 32 columns later
+      uint2 gg[NF], uu[NF];
+      bf16_t* grow = p.gu + (size_t)(mok ? m : 0) * (2 * p.Cn);
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn) {
+        int c = col0 + wn * NF * 16 + fn * 16 + g * 4;
+        c = c < p.Cn ? c : 0;
+        const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+        gg[fn] = *reinterpret_cast<const uint2*>(gp);
+        uu[fn] = *reinterpret_cast<const uint2*>(gp + 32);
+      }
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn) {
+        const int c = col0 + wn * NF * 16 + fn * 16 + g * 4;
+        f32x4_t d = acc[fm][fn];
+        const float gv[4] = {__uint_as_float(gg[fn].x << 16), __uint_as_float(gg[fn].x & 0xffff0000u),
+                             __uint_as_float(gg[fn].y << 16), __uint_as_float(gg[fn].y & 0xffff0000u)};
+        const float uv[4] = {__uint_as_float(uu[fn].x << 16), __uint_as_float(uu[fn].x & 0xffff0000u),
+                             __uint_as_float(uu[fn].y << 16), __uint_as_float(uu[fn].y & 0xffff0000u)};
+        float dg[4], du[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sg = 1.f / (1.f + __expf(-gv[r]));
+          du[r] = d[r] * gv[r] * sg;
+          dg[r] = d[r] * uv[r] * sg * (1.f + gv[r] * (1.f - sg));
+        }
+        if (mok && c < p.Cn) {
+          bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+          uint2 o1, o2;
+          o1.x = pack_bf16x2(dg[0], dg[1]); o1.y = pack_bf16x2(dg[2], dg[3]);
+          o2.x = pack_bf16x2(du[0], du[1]); o2.y = pack_bf16x2(du[2], du[3]);
+          *reinterpret_cast<uint2*>(gp) = o1;
+          *reinterpret_cast<uint2*>(gp + 32) = o2;
+        }
+      }
     } else {
       uint2 rr[4];
       if (p.resid) {
@@ -536,7 +573,7 @@ static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M,
             int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K & 7)) return -1;
-  GemmArgs a{X, W, Y, bias, resid, nullptr, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
+  GemmArgs a{X, W, Y, bias, resid, nullptr, nullptr, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (N + BN - 1) / BN};
   const bool dma_ok = (K % BK == 0) && (N % BN == 0);
   const int mode = dma_ok ? g_gemm_glds : 0;
@@ -563,7 +600,15 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
 
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
-  GemmArgs a{X, W, Y, nullptr, nullptr, act, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
+  GemmArgs a{X, W, Y, nullptr, nullptr, act, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
+  return launch<false, false, false, 2>(a, 1, st);
+}
+
+// d(act)[M,N] = dY[M,K] Wt[N,K]^T is never stored: gu [M,2N] (32-column gate/up blocks) is rewritten in
+// place with d(gate|up) = SwiGLU'(gate, up) * d(act).
+int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
+  if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
+  GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
   return launch<false, false, false, 2>(a, 1, st);
 }
 
@@ -571,7 +616,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st) {
   if (check_dims(M, K, N, N, K, K) || (N & 7)) return -1;
-  GemmArgs a{dY, W, dX, nullptr, resid, nullptr, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
+  GemmArgs a{dY, W, dX, nullptr, resid, nullptr, nullptr, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (K + BN - 1) / BN};
   return launch<false, true, false, 0>(a, 1, st);
 }
@@ -601,7 +646,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int splits = gemm_tn_splits(M, N, K);
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
-  GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
+  GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
   const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
   int e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
   if (e) return e;

@@ -16,6 +16,7 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st);
+int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st);
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);
