@@ -36,6 +36,8 @@ struct AttnArgs {
   float* dkv_part;     // [2][nH][M][64] fp32 per-q-head dK / dV partials
   const int* seg_start;  // [M]
   const int* seg_end;    // [M]
+  const float* rope_cs;  // nullable fp32 [M][32]: fold the transpose RoPE rotation into the dq / dk stores
+  const float* rope_sn;
   const int* perm;     // nullable: block rank -> q/key tile index, heaviest tiles first (attn_plan_kernel)
   int M, nH, nKV, ldq;
   float scale;         // head_dim^-0.5
@@ -250,26 +252,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// dsum[h][m] = sum_d dO[m][h*64+d] * O[m][h*64+d]
-__global__ __launch_bounds__(256) void attn_dsum_kernel(AttnArgs p) {
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)p.M * p.nH) return;
-  int m = (int)(idx / p.nH), h = (int)(idx % p.nH);
-  const uint4* a = reinterpret_cast<const uint4*>(p.d_o + (size_t)m * p.nH * 64 + h * 64);
-  const uint4* b = reinterpret_cast<const uint4*>(p.o + (size_t)m * p.nH * 64 + h * 64);
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float x[8], y[8];
-    unpack_bf16x8(a[c], x);
-    unpack_bf16x8(b[c], y);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += x[j] * y[j];
-  }
-  p.dsum[(size_t)h * p.M + m] = s;
-}
-
-// ------------------------------------------------------------------------------------------
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
 // Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
 constexpr int DQ_NST = 3;
@@ -309,14 +291,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const int qc = q < M ? q : M - 1;
   const int seg = p.seg_start[qc];
   const float lse = p.lse2[(size_t)h * M + qc];
-  const float dsm = p.dsum[(size_t)h * M + qc];
   const int segmax_w = p.seg_start[min(qw0 + 15, M - 1)];
   uint4 qf[2], dof[2];
+  float dsm = 0.f;  // D[q] = sum_d dO[q][d] * O[q][d]: each lane owns 16 of the 64 d's, 4 lanes per row
 #pragma unroll
   for (int ds = 0; ds < 2; ++ds) {
     qf[ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
     dof[ds] = *reinterpret_cast<const uint4*>(p.d_o + (size_t)qc * p.nH * 64 + h * 64 + g * 8 + 32 * ds);
+    uint4 of = *reinterpret_cast<const uint4*>(p.o + (size_t)qc * p.nH * 64 + h * 64 + g * 8 + 32 * ds);
+    float x[8], y[8];
+    unpack_bf16x8(dof[ds], x);
+    unpack_bf16x8(of, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsm += x[j] * y[j];
   }
+  dsm += __shfl_xor(dsm, 16, 64);
+  dsm += __shfl_xor(dsm, 32, 64);
+  if (g == 0 && q < M) p.dsum[(size_t)h * M + q] = dsm;  // consumed by the dK/dV kernel (launched after this one)
   f32x4_t dq[4];
 #pragma unroll
   for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -362,10 +353,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   if (q < M) {
 #pragma unroll
+    for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq[fd][r] *= p.scale;
+    if (p.rope_cs) {  // transpose rotation: d(pre-RoPE q); fragments fd and fd+2 hold d and d+32
+#pragma unroll
+      for (int fd = 0; fd < 2; ++fd) {
+        const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)q * 32 + fd * 16 + g * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)q * 32 + fd * 16 + g * 4);
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = dq[fd][r], b = dq[fd + 2][r];
+          dq[fd][r] = a * cc[r] + b * ss[r];
+          dq[fd + 2][r] = b * cc[r] - a * ss[r];
+        }
+      }
+    }
+#pragma unroll
     for (int fd = 0; fd < 4; ++fd) {
       uint2 o;
-      o.x = pack_bf16x2(dq[fd][0] * p.scale, dq[fd][1] * p.scale);
-      o.y = pack_bf16x2(dq[fd][2] * p.scale, dq[fd][3] * p.scale);
+      o.x = pack_bf16x2(dq[fd][0], dq[fd][1]);
+      o.y = pack_bf16x2(dq[fd][2], dq[fd][3]);
       *reinterpret_cast<uint2*>(p.dqkv + (size_t)q * ld + h * 64 + fd * 16 + g * 4) = o;
     }
   }
@@ -494,28 +503,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
-// dqkv[m][K head kvh / V head kvh] = bf16( sum over the group's query heads of the partials )
+// dqkv[m][K head kvh / V head kvh] = bf16( sum over the group's query heads of the partials ); a thread
+// owns d = 4c..4c+3 and its rotate-half partner d+32, so dK can be rotated back in the same pass.
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p) {
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (which, m, kvh, chunk of 4)
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (which, m, kvh, c < 8)
   const int grp = p.nH / p.nKV;
-  size_t total = (size_t)2 * p.M * p.nKV * 16;
+  size_t total = (size_t)2 * p.M * p.nKV * 8;
   if (idx >= total) return;
-  int c = idx & 15;
-  size_t r = idx >> 4;
+  int c = idx & 7;
+  size_t r = idx >> 3;
   int kvh = r % p.nKV; r /= p.nKV;
   int m = r % p.M;
   int which = (int)(r / p.M);
-  float4 s = make_float4(0, 0, 0, 0);
+  float4 a = make_float4(0, 0, 0, 0), b = a;
   for (int i = 0; i < grp; ++i) {
     int h = kvh * grp + i;
-    float4 v = *reinterpret_cast<const float4*>(p.dkv_part + (((size_t)which * p.nH + h) * p.M + m) * 64 + c * 4);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const float* src = p.dkv_part + (((size_t)which * p.nH + h) * p.M + m) * 64 + c * 4;
+    float4 v = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 32);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
   }
-  uint2 o;
-  o.x = pack_bf16x2(s.x, s.y);
-  o.y = pack_bf16x2(s.z, s.w);
+  if (which == 0 && p.rope_cs) {
+    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)m * 32 + c * 4);
+    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)m * 32 + c * 4);
+    float4 x = a, y = b;
+    a = make_float4(x.x * c4.x + y.x * s4.x, x.y * c4.y + y.y * s4.y, x.z * c4.z + y.z * s4.z, x.w * c4.w + y.w * s4.w);
+    b = make_float4(y.x * c4.x - x.x * s4.x, y.y * c4.y - x.y * s4.y, y.z * c4.z - x.z * s4.z, y.w * c4.w - x.w * s4.w);
+  }
+  uint2 o1, o2;
+  o1.x = pack_bf16x2(a.x, a.y); o1.y = pack_bf16x2(a.z, a.w);
+  o2.x = pack_bf16x2(b.x, b.y); o2.y = pack_bf16x2(b.z, b.w);
   int col = (p.nH + (which ? p.nKV : 0) + kvh) * 64 + c * 4;
-  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col) = o;
+  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col) = o1;
+  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col + 32) = o2;
 }
 
 // Longest-processing-time-first block order. Causal tiles differ 1:16 in work; in launch order the
@@ -586,22 +606,22 @@ int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, co
 size_t attn_bwd_workspace_bytes(int M, int nH) { return (size_t)2 * nH * M * 64 * sizeof(float); }
 
 int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum,
-             bf16_t* dqkv, float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, int M,
-             int nH, int nKV, int head_dim, hipStream_t st) {
+             bf16_t* dqkv, float* dkv_part, const int* seg_start, const int* seg_end, const int* plan,
+             const float* rope_cs, const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st) {
   if (head_dim != 64 || nH % nKV) return -1;
   AttnArgs a{};
   a.qkv = qkv; a.o = const_cast<bf16_t*>(o); a.d_o = d_o; a.dqkv = dqkv;
   a.lse2 = const_cast<float*>(lse2); a.dsum = dsum; a.dkv_part = dkv_part;
   a.seg_start = seg_start; a.seg_end = seg_end;
+  a.rope_cs = rope_cs; a.rope_sn = rope_sn;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
   if (int e = set_lds_attrs()) return e;
-  attn_dsum_kernel<<<(unsigned)(((size_t)M * nH + 255) / 256), 256, 0, st>>>(a);
   const int nf = (M + 127) / 128, nq = (M + 63) / 64;
   a.perm = plan ? plan + nf : nullptr;
   attn_bwd_dq_kernel<<<nq * nH, 256, DQ_NST * 3 * IMG, st>>>(a);
   a.perm = plan ? plan + nf + nq : nullptr;
   attn_bwd_dkv_kernel<<<nq * nH, 256, DKV_NST * DKV_STAGE, st>>>(a);
-  size_t total = (size_t)2 * M * nKV * 16;
+  size_t total = (size_t)2 * M * nKV * 8;
   attn_dkv_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
   return (int)hipGetLastError();
 }

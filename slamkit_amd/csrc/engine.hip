@@ -312,8 +312,12 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
-    CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
-    CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 0, st));
+    if ((H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
+      CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, nH + nKV, M, h->QKV, H, st));
+    } else {
+      CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
+      CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 0, st));
+    }
     CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
     CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
@@ -387,9 +391,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     // attention
     CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, M, nH, nKV,
-                d.head_dim, st));
-    CK(rope_apply(h->dqkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 1, st));
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->cosb, h->sinb, M,
+                nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, G + o.bqkv, 1, h->part_ws, st));
     CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
@@ -496,7 +499,7 @@ int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const floa
   int r = attn_plan(seg_start, seg_end, M, plan, (hipStream_t)s);
   if (r) return r;
   return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, dsum, (bf16_t*)dqkv, part, seg_start,
-                  seg_end, plan, M, nH, nKV, 64, (hipStream_t)s);
+                  seg_end, plan, nullptr, nullptr, M, nH, nKV, 64, (hipStream_t)s);
 }
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
                           float* scratch2, int B, int T, int V, slam_stream_t s) {

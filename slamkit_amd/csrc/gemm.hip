@@ -40,6 +40,11 @@ struct GemmArgs {
   int lda, ldb, ldc;
   int kc_per_split;
   int tiles_r, tiles_c;
+  // optional fused rotate-half RoPE on the first rope_heads 64-column heads (QKV projection epilogue):
+  // fp32 cos/sin tables [R][32]
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_heads;
 };
 
 SLAM_DEVICE uint32_t comp4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
@@ -392,21 +397,42 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
           rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + (n < p.Cn ? n : 0));
         }
       }
+      f32x4_t v[NF];
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn) {
+        v[fn] = acc[fm][fn];
+        if (p.bias) {
+          v[fn][0] += __uint_as_float(bb[fn].x << 16); v[fn][1] += __uint_as_float(bb[fn].x & 0xffff0000u);
+          v[fn][2] += __uint_as_float(bb[fn].y << 16); v[fn][3] += __uint_as_float(bb[fn].y & 0xffff0000u);
+        }
+        if (p.resid) {
+          v[fn][0] += __uint_as_float(rr[fn].x << 16); v[fn][1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+          v[fn][2] += __uint_as_float(rr[fn].y << 16); v[fn][3] += __uint_as_float(rr[fn].y & 0xffff0000u);
+        }
+      }
+      if constexpr (WAVES == 4) {
+        // fused RoPE: the wave's 64 columns are one head; fragments fn and fn+2 hold d and d+32
+        if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
+#pragma unroll
+          for (int fn = 0; fn < 2; ++fn) {
+            const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + fn * 16 + g * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + fn * 16 + g * 4);
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x1 = v[fn][r], x2 = v[fn + 2][r];
+              v[fn][r] = x1 * cc[r] - x2 * ss[r];
+              v[fn + 2][r] = x2 * cc[r] + x1 * ss[r];
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int fn = 0; fn < NF; ++fn) {
         const int n = col0 + wn * NF * 16 + fn * 16 + g * 4;
-        f32x4_t v = acc[fm][fn];
-        if (p.bias) {
-          v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
-          v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
-        }
-        if (p.resid) {
-          v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
-          v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
-        }
         uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
+        o.x = pack_bf16x2(v[fn][0], v[fn][1]);
+        o.y = pack_bf16x2(v[fn][2], v[fn][3]);
         if (mok && n < p.Cn) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
       }
       if constexpr (WAVES == 4) {
@@ -596,6 +622,14 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
     case 84: return launch<false, false, false, 4, 8>(a, 1, st);
     default: return launch<false, false, false, 0>(a, 1, st);
   }
+}
+
+// QKV projection with bias and rotate-half RoPE applied to the first rope_heads heads in the epilogue
+int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const float* cs, const float* sn,
+                 int rope_heads, int M, int N, int K, hipStream_t st) {
+  if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
+  GemmArgs a{X, W, Y, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN, cs, sn, rope_heads};
+  return launch<false, false, false, 2>(a, 1, st);
 }
 
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {

@@ -16,6 +16,8 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st);
+int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const float* cs, const float* sn,
+                 int rope_heads, int M, int N, int K, hipStream_t st);
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st);
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st);
@@ -30,9 +32,11 @@ int attn_plan(const int* seg_start, const int* seg_end, int M, int* plan, hipStr
 int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH, int nKV,
              int head_dim, hipStream_t st);
 size_t attn_bwd_workspace_bytes(int M, int nH);
+// rope_cs / rope_sn (nullable): fp32 [M][32] tables; when given, dq and dk are written already
+// rotated back (transpose rotation), i.e. as gradients of the pre-RoPE projections
 int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum, bf16_t* dqkv,
-             float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, int M, int nH, int nKV,
-             int head_dim, hipStream_t st);
+             float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, const float* rope_cs,
+             const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st);
 
 // elementwise.hip
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
