@@ -120,10 +120,10 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t 
 //      products only reach output rows that are never stored. ---------------------------------
 // Per-lane byte offsets (tile-invariant) of the 4 chunks a lane moves; the K-loop only advances the
 // wave-uniform base pointer G + k0.
-template <int THREADS>
+template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* voff) {
 #pragma unroll
-  for (int i = 0; i < 1024 / THREADS; ++i) {
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
     int P = i * THREADS + tid;
     int row = P >> 3, cs = P & 7;
     int c = cs ^ lds_swz_key(row);
@@ -132,11 +132,11 @@ SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* vo
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
-template <int THREADS>
+template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const uint32_t* voff, int wave,
                            uint32_t tile_lds) {
 #pragma unroll
-  for (int i = 0; i < 1024 / THREADS; ++i)
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i)
     glds16_sv(Gk, voff[i], __builtin_amdgcn_readfirstlane(tile_lds + (uint32_t)(i * THREADS + wave * 64) * 16u));
 }
 
@@ -149,12 +149,12 @@ SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const 
 //      a 32-lane group touches fall into 8 distinct 32-B windows of the 256-B bank row. ----------
 SLAM_DEVICE int tr_key(int kc) { return (kc & 3) | (((kc >> 3) & 1) << 2); }
 
-template <int THREADS>
+template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 #pragma unroll
-  for (int i = 0; i < 1024 / THREADS; ++i) {
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
     int P = i * THREADS + tid;
-    int kc = P >> 4, cs = P & 15;
+    int kc = P / (ROWS / 8), cs = P % (ROWS / 8);
     int c = cs ^ (tr_key(kc) << 1);
     voff[i] = (uint32_t)(((size_t)kc * ld + row0 + c * 8) * sizeof(bf16_t));
   }
@@ -162,16 +162,21 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 
 // WAVES = 4: 2x2 waves of 64x64, 2 blocks/CU; WAVES = 8: 2x4 waves of 64x32, one block per CU with a
 // deeper DMA ring (same 2 waves per SIMD, more latency budget per tile).
-template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4>
+//             BMT = 256 (8 waves as 4x2 of 64x64): 256x128 tile, one block per CU, 33 % fewer L2->LDS bytes
+//             per flop - at ~1 PFLOP/s the 128x128 tile already pulls ~15 TB/s through the L2.
+template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4,
+          int BMT = 128>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool GLDS = NSTAGE > 0;
   constexpr int THREADS = WAVES * 64;
-  constexpr int NF = WAVES == 4 ? 4 : 2;  // 16-column fragments per wave
-  static_assert(WAVES == 4 || (WAVES == 8 && NSTAGE > 0), "8-wave blocks exist for the DMA ring only");
+  constexpr int WMN = BMT / 64, WNN = WAVES / WMN;  // wave grid
+  constexpr int NF = 8 / WNN;                        // 16-column fragments per wave
+  constexpr int A_BYTES = BMT * 128, STAGE = A_BYTES + TILE_BYTES;
+  static_assert((WAVES == 4 && BMT == 128) || (WAVES == 8 && NSTAGE > 0), "8-wave blocks exist for the DMA ring only");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = WAVES == 4 ? (wave >> 1) : (wave >> 2), wn = WAVES == 4 ? (wave & 1) : (wave & 3);
+  const int wm = wave / WNN, wn = wave % WNN;
   const int l15 = lane & 15, g = lane >> 4;
 
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
     int q = nblk >> 3, r = nblk & 7;
     nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int row0 = (nid / p.tiles_c) * BM;
+  const int row0 = (nid / p.tiles_c) * BMT;
   const int col0 = (nid % p.tiles_c) * BN;
   const int kbeg = blockIdx.z * p.kc_per_split;
   const int kend = min(p.Kc, kbeg + p.kc_per_split);
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
   auto compute = [&](int s) {
-    const char* At = smem + s * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
+    const char* At = smem + s * STAGE;
+    const char* Bt = At + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
@@ -224,10 +229,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   // transposed-operand fragments: lane (l15, g) of fragment P (16 rows) at k-step kk reads
   // kc = kk*32 + g*8 + h*4 + (l15>>2), 8 bytes at row-block (P ^ key) and sub-offset (l15&3)*8
   const int trk = (l15 >> 2) | ((g & 1) << 2);
+  constexpr int PA = BMT * 2;  // bytes per kc row of the transposed A tile ([64 kc][BMT rows])
   const int tr_lane = (g * 8 + (l15 >> 2)) * 256 + (l15 & 3) * 8;
+  const int tr_lane_a = (g * 8 + (l15 >> 2)) * PA + (l15 & 3) * 8;
   auto compute_tr = [&](int s) {
-    const char* At = smem + s * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
+    const char* At = smem + s * STAGE;
+    const char* Bt = At + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 af[NF], bf[4];
@@ -239,8 +246,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const char* pb = At + tr_lane + kk * 32 * 256 + (((wm * 4 + f) ^ trk) << 5);
-        uint2 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * 256);
+        const char* pb = At + tr_lane_a + kk * 32 * PA + (((wm * 4 + f) ^ trk) << 5);
+        uint2 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * PA);
         bf[f] = make_uint4(b0.x, b0.y, b1.x, b1.y);
       }
 #pragma unroll
@@ -256,23 +263,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
     const uint32_t lds0 = lds_addr(smem);
     uint32_t voa[4], vob[4];
     if constexpr (TR) {
-      glds_offsets_tr<THREADS>(p.lda, row0, tid, voa);
-      glds_offsets_tr<THREADS>(p.ldb, col0, tid, vob);
+      glds_offsets_tr<THREADS, BMT>(p.lda, row0, tid, voa);
+      glds_offsets_tr<THREADS, BN>(p.ldb, col0, tid, vob);
     } else {
-      glds_offsets<THREADS>(p.lda, p.R, row0, tid, voa);
-      glds_offsets<THREADS>(p.ldb, p.Cn, col0, tid, vob);
+      glds_offsets<THREADS, BMT>(p.lda, p.R, row0, tid, voa);
+      glds_offsets<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
     }
-    constexpr int PT = 2 * (1024 / THREADS);  // DMAs per lane per tile
+    constexpr int PT = (BMT + BN) * 8 / THREADS;  // DMAs per lane per tile
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
-      const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
+      const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE);
       // wave-uniform bases: direct operands advance along the contiguous contraction dim, transposed
       // operands by whole rows
       const bf16_t* ga = TR ? p.A + (size_t)k0 * p.lda : p.A + k0;
       const bf16_t* gb = TR ? p.B + (size_t)k0 * p.ldb : p.B + k0;
-      glds_tile<THREADS>(ga, voa, wv, st);
-      glds_tile<THREADS>(gb, vob, wv, st + TILE_BYTES);
+      glds_tile<THREADS, BMT>(ga, voa, wv, st);
+      glds_tile<THREADS, BN>(gb, vob, wv, st + A_BYTES);
     };
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
           v[fn][2] += __uint_as_float(rr[fn].y << 16); v[fn][3] += __uint_as_float(rr[fn].y & 0xffff0000u);
         }
       }
-      if constexpr (WAVES == 4) {
+      if constexpr (NF == 4) {
         // fused RoPE: the wave's 64 columns are one head; fragments fn and fn+2 hold d and d+32
         if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
 #pragma unroll
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
         o.y = pack_bf16x2(v[fn][2], v[fn][3]);
         if (mok && n < p.Cn) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
       }
-      if constexpr (WAVES == 4) {
+      if constexpr (NF == 4) {
         // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up]; fragments fn and fn+2 of a lane
         // hold gate and up of the same 4 activation columns
         if (p.act && mok) {
@@ -506,13 +513,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt32_kernel(GemmArgs p) {
   };
   const uint32_t lds0 = lds_addr(smem);
   uint32_t voa[4], vob[4];
-  glds_offsets<256>(p.lda, p.R, row0, tid, voa);
-  glds_offsets<256>(p.ldb, p.Cn, col0, tid, vob);
+  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
+  glds_offsets<256, 128>(p.ldb, p.Cn, col0, tid, vob);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int t) {
     const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
-    glds_tile<256>(p.A + t * BK, voa, wv, st);
-    glds_tile<256>(p.B + t * BK, vob, wv, st + TILE_BYTES);
+    glds_tile<256, 128>(p.A + t * BK, voa, wv, st);
+    glds_tile<256, 128>(p.B + t * BK, vob, wv, st + TILE_BYTES);
   };
   if (nk > 0) issue(0);
   for (int t = 0; t < nk; ++t) {
@@ -564,18 +571,19 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
-template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4>
-int launch(const GemmArgs& a, int splits, hipStream_t st) {
-  constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * STAGE_BYTES;
+template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128>
+int launch(GemmArgs a, int splits, hipStream_t st) {
+  constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * (BMT * 128 + TILE_BYTES);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  a.tiles_r = (a.R + BMT - 1) / BMT;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES><<<grid, WAVES * 64, lds, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT><<<grid, WAVES * 64, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -618,6 +626,9 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
       gemm_nt32_kernel<<<a.tiles_r * a.tiles_c, 256, 2 * STAGE_BYTES, st>>>(a);
       return (int)hipGetLastError();
     }
+    case 82: return launch<false, false, false, 2, 8>(a, 1, st);
+    case 162: return launch<false, false, false, 2, 8, 256>(a, 1, st);
+    case 163: return launch<false, false, false, 3, 8, 256>(a, 1, st);
     case 83: return launch<false, false, false, 3, 8>(a, 1, st);
     case 84: return launch<false, false, false, 4, 8>(a, 1, st);
     default: return launch<false, false, false, 0>(a, 1, st);
@@ -635,6 +646,9 @@ int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, nullptr, nullptr, act, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
+  // wide-N, short-K projection: the 256x128 tile / 3-stage ring measured +16 % here (740 vs 640 TFLOP/s at
+  // M 8192, N 9728, K 896); every other Slam shape is as fast or faster on the 128x128 kernel
+  if (g_gemm_glds == 2 && M >= 2048 && N >= 4096) return launch<false, false, false, 3, 8, 256>(a, 1, st);
   return launch<false, false, false, 2>(a, 1, st);
 }
 

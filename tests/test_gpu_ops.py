@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("glds", [0, 1, 3, 4, 32, 83, 84])
+@pytest.mark.parametrize("glds", [0, 1, 3, 4, 32, 83, 84, 162, 163])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 256, 128), (1000, 1152, 896),
                                    (74, 512, 256)])
 def test_gemm_nt(M, N, K, glds):
