@@ -12,6 +12,7 @@ xGMI on ROCm; "gloo" on CPU for tests). Replaces torch DDP's reducer (SURVEY.md 
 """
 from __future__ import annotations
 
+import os
 from typing import Iterator, List, Optional, Sequence
 
 import torch
@@ -31,9 +32,21 @@ def host_group():
     """A gloo group for host-side scalars (token counts, stop flags): keeps tiny collectives off the
     GPU streams. All ranks must call this at the same point (SLAMTrainer.__init__)."""
     global _HOST_GROUP
-    if _HOST_GROUP is None and dist.is_initialized() and dist.get_world_size() > 1:
-        _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
-    return _HOST_GROUP
+    force = os.environ.get("SLAM_DP_FORCE", "0") == "1"
+    if _HOST_GROUP is None and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        if dist.get_backend() == "gloo":
+            _HOST_GROUP = dist.group.WORLD
+        else:
+            # single-node rendezvous on 127.0.0.1: pin gloo to loopback (the container hostname may not resolve)
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            try:
+                _HOST_GROUP = dist.new_group(backend="gloo")
+            except Exception as e:  # noqa: BLE001 - fall back to device-side scalars on the default group
+                import logging
+                logging.getLogger(__name__).warning(f"gloo side group unavailable ({e}); using the RCCL group for scalars")
+                _HOST_GROUP = False
+    return _HOST_GROUP or None
 
 
 class GradBucketReducer:
@@ -44,12 +57,14 @@ class GradBucketReducer:
         self.pending = []
         self.ranges = []
         self.side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        # SLAM_DP_FORCE=1: run the collective path even on a single rank (exercises RCCL on a 1-GPU box)
+        self.force = os.environ.get("SLAM_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
     def on_bucket(self, offset: int, count: int):
         """Called by the engine (host side) right after the kernels producing grads[offset:offset+count]
         were enqueued on the current stream."""
         self.ranges.append((offset, count))
-        if self.world == 1 or count <= 0:
+        if (self.world == 1 and not self.force) or count <= 0:
             return
         view = self.flat[offset:offset + count]
         if self.side is not None:

@@ -50,7 +50,7 @@ class SLAMTrainer:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.reducer = GradBucketReducer(model.flat_grads)
-        self.host_group = host_group() if self.world > 1 else None
+        self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
         self.opt_step = 0
@@ -73,7 +73,7 @@ class SLAMTrainer:
                             position_ids=inputs.get("position_ids"), labels=inputs["labels"],
                             num_items_in_batch=num_items_in_batch, return_logits=False)
         loss = out.loss.detach()
-        if last_micro and self.world > 1:
+        if last_micro and (self.world > 1 or self.reducer.force):
             model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
         else:
             model.backward(grad_scale)
@@ -115,11 +115,15 @@ class SLAMTrainer:
                 local_seen = local_items
             else:
                 local_seen = float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
-        if self.world > 1:
+        if self.world > 1 or self.reducer.force:
             # host-side (gloo) all-reduce: the counts come from CPU labels, and a device collective here
             # would stall the host behind the previous step's kernels
-            t = torch.tensor([local_items, local_seen], dtype=torch.float64)
-            dist.all_reduce(t, group=self.host_group)
+            if self.host_group is not None:
+                t = torch.tensor([local_items, local_seen], dtype=torch.float64)
+                dist.all_reduce(t, group=self.host_group)
+            else:  # no gloo: device collective on the RCCL group (costs one host sync per step)
+                t = torch.tensor([local_items, local_seen], dtype=torch.float64, device=self.model.device)
+                dist.all_reduce(t)
             glob_items, glob_seen = (float(x) for x in t.tolist())
         else:
             glob_items, glob_seen = local_items, local_seen
