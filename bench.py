@@ -11,7 +11,7 @@ overlapped with backward) + global-norm clip 0.5 + AdamW, on synthetic unit-toke
 resident in HBM. Weak scaling (per-GPU work fixed). Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
-  roofline     - dominant kernel (the gate|up projection GEMM, M=8192 N=9728 K=896): algorithmic flops per
+  roofline     - dominant kernel (the gate|up projection GEMM with fused SwiGLU, M=8192 N=9728 K=896): algorithmic flops per
                  launch / mean launch time measured here with HIP events on the launch stream, against the
                  2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md). `step_frac` is the whole-step
                  figure: tokens/s x 2.282 GFLOP/token / peak.
@@ -53,19 +53,21 @@ def dominant_kernel_roofline(model, iters=20):
     x = (torch.randn(M, K, device=model.device) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device=model.device) * 0.02).to(torch.bfloat16)
     y = torch.empty(M, N, dtype=torch.bfloat16, device=model.device)
+    act = torch.empty(M, N // 2, dtype=torch.bfloat16, device=model.device)
     st = E.current_stream_ptr()
     for _ in range(3):
-        lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 1, st)
+        lib.slam_op_gemm_nt_swiglu(x.data_ptr(), w.data_ptr(), y.data_ptr(), act.data_ptr(), M, N, K, st)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 1, st)
+        lib.slam_op_gemm_nt_swiglu(x.data_ptr(), w.data_ptr(), y.data_ptr(), act.data_ptr(), M, N, K, st)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<nt,glds> gate|up M8192 N9728 K896", "achieved": round(ach, 1),
+    return {"bound": "mfma", "kernel": "gemm_kernel<NT, DMA ring 3, 8 waves, 256x128> gate|up + fused SwiGLU, M8192 N9728 K896",
+            "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4), "traffic": None}
 

@@ -121,6 +121,9 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value); /* "gemm_gld
 /* ---- single-op entry points (parity tests call each kernel through the ABI) -------------------*/
 int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
                     int use_glds, slam_stream_t s);
+/* gate|up projection with the SwiGLU product fused into the epilogue (W rows in 32-row gate/up blocks):
+ * Y[M,N] = X W^T and act[M,N/2] = silu(gate) * up. The dominant kernel of the step (bench.py roofline). */
+int slam_op_gemm_nt_swiglu(const void* X, const void* W, void* Y, void* act, int M, int N, int K, slam_stream_t s);
 int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s);
 size_t slam_op_gemm_tn_workspace(int M, int N, int K);
 int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,

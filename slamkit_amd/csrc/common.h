@@ -38,6 +38,9 @@ SLAM_DEVICE uint4 pack_bf16x8(const float* f) {
 // raw v_exp_f32 (2^x): no denormal-range fix-up code (arguments here are <= 0 or moderate)
 SLAM_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// sigmoid via v_exp_f32 + v_rcp_f32 (about 1 ulp each): 4 VALU ops instead of an IEEE division sequence
+SLAM_DEVICE float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp2(-1.44269504088896340736f * x)); }
+
 SLAM_DEVICE float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
   unpack_bf16x8(*reinterpret_cast<const uint4*>(row), g);
   unpack_bf16x8(*reinterpret_cast<const uint4*>(row + blk), u);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+  for (int j = 0; j < 8; ++j) o[j] = g[j] * fast_sigmoid(g[j]) * u[j];
   *reinterpret_cast<uint4*>(act + m * I + c * 8) = pack_bf16x8(o);
 }
 
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(bf16_t* __restrict__ gu
   unpack_bf16x8(*reinterpret_cast<const uint4*>(dact + m * I + c * 8), d);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float sg = 1.f / (1.f + __expf(-g[j]));
+    float sg = fast_sigmoid(g[j]);
     float silu = g[j] * sg;
     du[j] = d[j] * silu;
     dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));

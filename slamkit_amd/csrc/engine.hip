@@ -65,7 +65,7 @@ struct SlamEngine {
   // last forward
   int B = 0, T = 0;
   bool have_fwd = false, have_loss = false;
-  bool fuse_swiglu = false;
+  bool fuse_swiglu = false, fuse_dswiglu = true;
   const int64_t* last_ids = nullptr;
   const int* cur_seg_s = nullptr;
   const int* cur_seg_e = nullptr;
@@ -276,8 +276,10 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!key) return SLAM_EINVAL;
   if (!strcmp(key, "gemm_glds")) { gemm_set_glds((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_dma")) { gemm_set_tn_dma((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_group_rows")) { gemm_set_group_rows((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
 }
 
@@ -379,7 +381,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     LayerAct& a = h->la[l];
     // MLP
     CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
-    if (Pt && h->fuse_swiglu && (I % 128 == 0) && (H % 64 == 0)) {
+    if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
     } else {
       CK(dgrad(dh, o.wd, h->dact, H, I));
@@ -454,6 +456,9 @@ int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, con
                   (hipStream_t)s);
   gemm_set_glds(1);
   return r;
+}
+int slam_op_gemm_nt_swiglu(const void* X, const void* W, void* Y, void* act, int M, int N, int K, slam_stream_t s) {
+  return gemm_nt_swiglu((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (bf16_t*)act, M, N, K, (hipStream_t)s);
 }
 int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s) {
   return gemm_nn((const bf16_t*)dY, (const bf16_t*)W, (bf16_t*)dX, (const bf16_t*)resid, M, N, K, (hipStream_t)s);

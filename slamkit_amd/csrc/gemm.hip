@@ -45,6 +45,7 @@ struct GemmArgs {
   const float* rope_cos;
   const float* rope_sin;
   int rope_heads;
+  int group_rows;  // tile rasterisation group height (0/1 = plain row-major)
 };
 
 SLAM_DEVICE uint32_t comp4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
@@ -188,8 +189,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
     int q = nblk >> 3, r = nblk & 7;
     nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int row0 = (nid / p.tiles_c) * BMT;
-  const int col0 = (nid % p.tiles_c) * BN;
+  // grouped rasterisation inside an XCD's run: GR row-tiles x all column tiles per group, column-major
+  // inside the group, so the tiles in flight on one XCD share GR row panels and a few column panels
+  // (the weight matrix of the wide projections does not fit the 4 MB L2: measured 590 MB of L2-miss
+  // reads per gate|up launch with row-major order, 32 MB algorithmic)
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);  // last group may be short
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * BMT;
+  const int col0 = tc_ * BN;
   const int kbeg = blockIdx.z * p.kc_per_split;
   const int kend = min(p.Kc, kbeg + p.kc_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
         float dg[4], du[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sg = 1.f / (1.f + __expf(-gv[r]));
+          float sg = fast_sigmoid(gv[r]);
           du[r] = d[r] * gv[r] * sg;
           dg[r] = d[r] * uv[r] * sg * (1.f + gv[r] * (1.f - sg));
         }
@@ -450,8 +464,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
           for (int fn = 0; fn < 2; ++fn) {
             const int ac = (col0 + wn * 64) / 2 + fn * 16 + g * 4;
             f32x4_t gt = acc[fm][fn], up = acc[fm][fn + 2];
-            float a0 = gt[0] / (1.f + __expf(-gt[0])) * up[0], a1 = gt[1] / (1.f + __expf(-gt[1])) * up[1];
-            float a2 = gt[2] / (1.f + __expf(-gt[2])) * up[2], a3 = gt[3] / (1.f + __expf(-gt[3])) * up[3];
+            float a0 = gt[0] * fast_sigmoid(gt[0]) * up[0], a1 = gt[1] * fast_sigmoid(gt[1]) * up[1];
+            float a2 = gt[2] * fast_sigmoid(gt[2]) * up[2], a3 = gt[3] * fast_sigmoid(gt[3]) * up[3];
             uint2 o;
             o.x = pack_bf16x2(a0, a1);
             o.y = pack_bf16x2(a2, a3);
@@ -571,6 +585,8 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
+static int g_group_rows = 4;  // step-level A/B on MI355X: 1 -> 35.5 ms, 4 -> 34.7, 8 -> 36.2, 16 -> 36.5
+
 template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128>
 int launch(GemmArgs a, int splits, hipStream_t st) {
   constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * (BMT * 128 + TILE_BYTES);
@@ -582,6 +598,7 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
     attr_set = true;
   }
   a.tiles_r = (a.R + BMT - 1) / BMT;
+  a.group_rows = g_group_rows;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
   gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT><<<grid, WAVES * 64, lds, st>>>(a);
   return (int)hipGetLastError();
@@ -596,6 +613,7 @@ static int g_gemm_glds = 2;
 static int g_gemm_tn_dma = 1;
 void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
 void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
+void gemm_set_group_rows(int g) { g_group_rows = g; }
 
 static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
   if (R <= 0 || Cn <= 0 || Kc <= 0) return -1;
@@ -646,9 +664,9 @@ int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, nullptr, nullptr, act, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  // wide-N, short-K projection: the 256x128 tile / 3-stage ring measured +16 % here (740 vs 640 TFLOP/s at
-  // M 8192, N 9728, K 896); every other Slam shape is as fast or faster on the 128x128 kernel
-  if (g_gemm_glds == 2 && M >= 2048 && N >= 4096) return launch<false, false, false, 3, 8, 256>(a, 1, st);
+  // (the 256x128 / 3-stage variant, mode 163, was +16 % here before the grouped tile order; with it the
+  //  128x128 kernel is faster again: 866 vs 782 TFLOP/s at M 8192, N 9728, K 896)
+  if (g_gemm_glds == 163) return launch<false, false, false, 3, 8, 256>(a, 1, st);
   return launch<false, false, false, 2>(a, 1, st);
 }
 

@@ -156,6 +156,10 @@ class UnitLM(TokenLM):
             self._ensure_workspace(config.max_tokens)
             self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        for opt in ("fuse_swiglu", "fuse_dswiglu", "gemm_group_rows", "gemm_glds", "gemm_tn_splits"):  # tuning overrides, e.g. SLAM_FUSE_SWIGLU=0
+            v = os.environ.get("SLAM_" + opt.upper())
+            if v is not None:
+                self.engine.set_option(opt, int(v))
         self.training = True
         self._build_key_map()
         self.init_weights(seed)

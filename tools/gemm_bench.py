@@ -36,9 +36,11 @@ for name, (N, K) in {"qkv fwd": (1152, 896), "o fwd/dgrad": (896, 896), "gate_up
                      "down fwd": (896, 4864), "qkv dgrad": (896, 1152), "down dgrad": (4864, 896),
                      "gate_up dgrad": (896, 9728)}.items():
     x, w, y = rb(M, K), rb(N, K), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for mode in (2, 162, 163):
+    for mode, gr in ((2, 1), (2, 4), (2, 8), (2, 16), (163, 1), (163, 4), (163, 8)):
+        lib.slam_set_option(None, b"gemm_group_rows", gr)
         us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, mode, st))
-        print(f"nt {name:25s} {mode:5d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
+        print(f"nt {name:25s} {mode:5d} gr={gr:2d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
+    lib.slam_set_option(None, b"gemm_group_rows", 4)
 for name, (N, K) in {"wqkv": (1152, 896), "wo": (896, 896), "wgu": (9728, 896), "wd": (896, 4864)}.items():
     dy, x = rb(M, N), rb(M, K)
     ws = torch.empty(lib.slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device=dev)
