@@ -106,6 +106,12 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
 int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, float* ll_out, float* cnt_out,
                     slam_stream_t stream);
 
+/* Sequence-level objectives on top of the token log-likelihoods (preference optimisation, TRL DPOTrainer
+ * behind /root/reference cli/preference_alignment_train.py:56-65): after a forward with labels and
+ * num_items = 1 (so d loss/d logits holds softmax - onehot per valid token), multiply the rows of sequence b
+ * by seq_coef[b] (fp32 [B] device) - e.g. +-beta*sigmoid(-x)/n for the sigmoid DPO loss - then slam_backward. */
+int slam_scale_loss_rows(SlamEngine* h, const float* seq_coef, int32_t B, int32_t T, slam_stream_t stream);
+
 /* ---- optimizer step: HF Trainer clip_grad_norm_ + torch AdamW --------------
  * norm_out: fp32 [2] device = {global grad norm, clip coefficient}. */
 int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream);

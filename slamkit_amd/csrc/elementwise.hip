@@ -416,6 +416,20 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const bf16_t* __restrict
   dst[m * ldd + c] = src[m * lds_ + c];
 }
 
+// dlogits[m][:] *= coef[m / T]  (per-sequence loss weights: DPO's +-beta*sigmoid(-x)/n)
+__global__ __launch_bounds__(256) void scale_rows_bf16_kernel(bf16_t* __restrict__ x, const float* __restrict__ coef,
+                                                              size_t M, int T, int chunks_per_row) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * chunks_per_row) return;
+  const float s = coef[(i / chunks_per_row) / T];
+  float f[8];
+  uint4* p = reinterpret_cast<uint4*>(x) + i;
+  unpack_bf16x8(*p, f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] *= s;
+  *p = pack_bf16x8(f);
+}
+
 __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x, size_t nchunks, float s) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunks) return;
@@ -619,6 +633,11 @@ int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float
 }
 int copy_cols(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int ncols, hipStream_t st) {
   copy_cols_kernel<<<nblocks((size_t)M * ncols, 256), 256, 0, st>>>(src, lds_, dst, ldd, (size_t)M, ncols);
+  LAUNCH_RET();
+}
+int scale_rows_bf16(bf16_t* x, const float* coef, int M, int T, int ncols, hipStream_t st) {
+  if (ncols & 7) return -1;
+  scale_rows_bf16_kernel<<<nblocks((size_t)M * (ncols / 8), 256), 256, 0, st>>>(x, coef, (size_t)M, T, ncols / 8);
   LAUNCH_RET();
 }
 int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st) {

@@ -420,6 +420,13 @@ int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, 
   return SLAM_OK;
 }
 
+int slam_scale_loss_rows(SlamEngine* h, const float* seq_coef, int32_t B, int32_t T, slam_stream_t stream) {
+  if (!h || !seq_coef) return SLAM_EINVAL;
+  if (!h->have_loss || B != h->B || T != h->T) return h->fail(SLAM_ESTATE, "scale_loss_rows needs the matching forward with labels");
+  CK(scale_rows_bf16(h->dlogits, seq_coef, B * T, T, VPAD, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
 int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream) {
   if (!h || !norm_out) return SLAM_EINVAL;
   if (!h->grads || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");

@@ -65,6 +65,7 @@ def load_library(path: Optional[str] = None):
         "slam_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
         "slam_backward": (C.c_int, [vp, f32, i32, BUCKET_CB, vp, vp]),
         "slam_seq_loglik": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+        "slam_scale_loss_rows": (C.c_int, [vp, vp, i32, i32, vp]),
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
         "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
@@ -201,6 +202,10 @@ class Engine:
     def seq_loglik(self, labels, B, T, ll_out, cnt_out, stream=None):
         self._ck(self.lib.slam_seq_loglik(self.h, _ptr(labels), B, T, _ptr(ll_out), _ptr(cnt_out),
                                           stream if stream is not None else current_stream_ptr()))
+
+    def scale_loss_rows(self, seq_coef, B, T, stream=None):
+        self._ck(self.lib.slam_scale_loss_rows(self.h, _ptr(seq_coef), B, T,
+                                               stream if stream is not None else current_stream_ptr()))
 
     def grad_norm(self, max_norm: float, norm_out, stream=None):
         self._ck(self.lib.slam_grad_norm(self.h, float(max_norm), _ptr(norm_out),

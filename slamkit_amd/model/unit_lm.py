@@ -368,6 +368,28 @@ class UnitLM(TokenLM):
         self.engine.seq_loglik(lab, B, T, ll, cnt)
         return ll / cnt if mean_nll else ll
 
+    def sequence_logps(self, input_ids: torch.Tensor, labels: torch.Tensor):
+        """Per-sequence sums of target log-probs over the non-ignored labels (what TRL's DPOTrainer calls
+        `chosen_logps` / `rejected_logps`). Leaves the engine ready for `scale_loss_rows` + `backward`:
+        d(-logp_b)/dlogits is stored unscaled (num_items = 1)."""
+        B, T = input_ids.shape
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        lab = labels.to(self.device, torch.int64).contiguous()
+        self._ensure_workspace(B * T)
+        self._hold = (ids, lab)
+        self.engine.forward(ids, lab, None, None, None, B, T, 1.0, self._loss_buf, None)
+        ll = torch.empty(B, dtype=torch.float32, device=self.device)
+        cnt = torch.empty(B, dtype=torch.float32, device=self.device)
+        self.engine.seq_loglik(lab, B, T, ll, cnt)
+        return ll, cnt
+
+    def backward_sequence_loss(self, seq_coef: torch.Tensor, B: int, T: int, grad_scale: float = 1.0, **kw):
+        """Backward of sum_b seq_coef[b] * (-logp_b): seq_coef = d loss / d(-logp_b)."""
+        coef = seq_coef.to(self.device, torch.float32).contiguous()
+        self._hold = self._hold + (coef,)
+        self.engine.scale_loss_rows(coef, B, T)
+        self.engine.backward(grad_scale, kw.get("bucket_layers", 0), kw.get("bucket_cb"))
+
     @torch.no_grad()
     def generate(self, inputs: Optional[torch.Tensor] = None, generation_config=None, max_new_tokens: int = 32,
                  do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, seed: Optional[int] = None,

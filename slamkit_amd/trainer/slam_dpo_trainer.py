@@ -1,0 +1,115 @@
+"""Preference optimisation (DPO) on the HIP engine: /root/reference cli/preference_alignment_train.py:18-65
++ slamkit/trainer/slam_dpo_trainer.py:4-64 (tokenize_row) + TRL's sigmoid DPO loss (TRL is absent here:
+the loss is restated from its definition, SURVEY.md §8c - parity for it is unpinned, tokenize_row is pinned).
+
+Policy and frozen reference model are both `slamkit_amd.model.UnitLM`; one optimizer step =
+  policy forward on [chosen; rejected] (2B sequences) -> per-sequence completion log-probs (slam_seq_loglik)
+  reference forward (no gradients)                   -> ref log-probs
+  x = beta * ((pi_c - pi_r) - (ref_c - ref_r)); loss = mean(-log sigmoid(x))
+  d loss / d(-logp) per sequence -> slam_scale_loss_rows -> slam_backward -> clip + AdamW
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .slam_trainer import SLAMTrainer
+from .training_args import SLAMTrainingArguments
+
+
+@dataclass
+class DPOConfig(SLAMTrainingArguments):
+    """config/training_args/dpo_training_args.yaml: lr 5e-5, beta 0.1."""
+    beta: float = 0.1
+    max_prompt_length: Optional[int] = 512
+    max_completion_length: Optional[int] = None
+    max_length: Optional[int] = 1024
+    learning_rate: float = 5e-5
+
+
+class SLAMDPOTrainer(SLAMTrainer):
+    @staticmethod
+    def tokenize_row(features, processing_class, max_prompt_length, max_completion_length, add_special_tokens=False):
+        """slam_dpo_trainer.py:7-64: prompt = [bos] + ids (left-truncated), completions = ids + [eos]
+        (right-truncated); strings are tokenised without special tokens."""
+        tokenizer = processing_class  # the UnitTokeniser itself, as preference_alignment_train.py:56-58 passes it
+        enc = lambda s: list(tokenizer(s, add_special_tokens=False)["input_ids"])  # noqa: E731
+        prompt_input_ids = [tokenizer.bos_token_id] + enc(features["prompt"])
+        if add_special_tokens and tokenizer.eos_token_id is not None:
+            prompt_input_ids = prompt_input_ids + [tokenizer.eos_token_id]
+        chosen_input_ids = enc(features["chosen"]) + [tokenizer.eos_token_id]
+        rejected_input_ids = enc(features["rejected"]) + [tokenizer.eos_token_id]
+        if max_prompt_length is not None:
+            prompt_input_ids = prompt_input_ids[-max_prompt_length:]
+        if max_completion_length is not None:
+            chosen_input_ids = chosen_input_ids[:max_completion_length]
+            rejected_input_ids = rejected_input_ids[:max_completion_length]
+        return {"prompt_input_ids": prompt_input_ids, "chosen_input_ids": chosen_input_ids,
+                "rejected_input_ids": rejected_input_ids}
+
+    def __init__(self, model=None, ref_model=None, args: DPOConfig = None, train_dataset=None, eval_dataset=None,
+                 processing_class=None, callbacks=None):
+        args = args or DPOConfig()
+        rows = [self.tokenize_row(r, processing_class, args.max_prompt_length, args.max_completion_length)
+                for r in train_dataset]
+        super().__init__(model=model, args=args, data_collator=self._collate_pairs, train_dataset=rows,
+                         eval_dataset=eval_dataset, processing_class=processing_class, callbacks=callbacks)
+        self.ref_model = ref_model
+        self.pad_id = model.config.pad_token_id
+
+    def _collate_pairs(self, rows: List[Dict[str, List[int]]]) -> Dict[str, torch.Tensor]:
+        """[chosen rows; rejected rows], right-padded; labels = completion tokens only (prompt and pad -> -100)."""
+        seqs, labs = [], []
+        for key in ("chosen_input_ids", "rejected_input_ids"):
+            for r in rows:
+                ids = (r["prompt_input_ids"] + r[key])
+                lab = [-100] * len(r["prompt_input_ids"]) + list(r[key])
+                if self.args.max_length is not None:
+                    ids, lab = ids[: self.args.max_length], lab[: self.args.max_length]
+                seqs.append(ids)
+                labs.append(lab)
+        T = max(len(s) for s in seqs)
+        ids = torch.full((len(seqs), T), self.pad_id, dtype=torch.long)
+        lab = torch.full((len(seqs), T), -100, dtype=torch.long)
+        for i, (s, l) in enumerate(zip(seqs, labs)):
+            ids[i, : len(s)] = torch.tensor(s)
+            lab[i, : len(l)] = torch.tensor(l)
+        return {"input_ids": ids, "labels": lab}
+
+    @staticmethod
+    def dpo_loss(pi_c, pi_r, ref_c, ref_r, beta: float):
+        x = beta * ((pi_c - pi_r) - (ref_c - ref_r))
+        return -F.logsigmoid(x), x
+
+    def optimizer_step(self, micro, lr: float, counts=None):
+        a = self.args
+        nm = len(micro)
+        for i, mb in enumerate(micro):
+            ids, lab = mb["input_ids"], mb["labels"]
+            B2, T = ids.shape
+            n = B2 // 2
+            with torch.no_grad():
+                ref, _ = self.ref_model.sequence_logps(ids, lab)
+                ref = ref.clone()
+            pol, _ = self.model.sequence_logps(ids, lab)
+            losses, x = self.dpo_loss(pol[:n], pol[n:], ref[:n], ref[n:], a.beta)
+            # d mean(loss) / d(-logp): chosen +beta*sigmoid(-x)/n, rejected -beta*sigmoid(-x)/n
+            g = a.beta * torch.sigmoid(-x) / (n * nm * self.world)
+            coef = torch.cat([g, -g])
+            last = i == nm - 1
+            self.model.backward_sequence_loss(coef, B2, T, 1.0,
+                                              bucket_layers=a.ddp_bucket_layers if (last and self.world > 1) else 0,
+                                              bucket_cb=self.reducer.on_bucket if (last and self.world > 1) else None)
+            self._loss_acc += losses.mean().detach() / nm
+            self.state.num_input_tokens_seen += int((lab != -100).sum()) * self.world
+        self._loss_n += 1
+        self.reducer.finish()
+        eng = self.model.engine
+        eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
+        self.opt_step += 1
+        eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
+                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=True)
+        self.state.global_step += 1

@@ -152,6 +152,26 @@ out["pad_logits_bf16_rmsrel"] = np.float32(
     ((ob.logits.float() - torch.from_numpy(out["pad_logits"])).pow(2).mean().sqrt()
      / torch.from_numpy(out["pad_logits"]).pow(2).mean().sqrt()).item())
 
+# ---- G9: SLAMDPOTrainer.tokenize_row (slam_dpo_trainer.py:7-64), loaded by file path over a stub `trl` ----
+import importlib.util  # noqa: E402
+import types  # noqa: E402
+trl_stub = types.ModuleType("trl")
+trl_stub.DPOTrainer = type("DPOTrainer", (), {})
+sys.modules["trl"] = trl_stub
+spec = importlib.util.spec_from_file_location("ref_slam_dpo_trainer", os.path.join(REF, "slamkit", "trainer", "slam_dpo_trainer.py"))
+mod = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mod)
+gg = torch.Generator().manual_seed(21)
+g9 = []
+for i in range(6):
+    mk = lambda n: "".join(f"<Un{int(u)}>" for u in torch.randint(0, 500, (n,), generator=gg))  # noqa: E731
+    feats = {"prompt": mk(int(torch.randint(3, 12, (1,), generator=gg))), "chosen": mk(int(torch.randint(2, 9, (1,), generator=gg))),
+             "rejected": mk(int(torch.randint(2, 9, (1,), generator=gg)))}
+    mp, mc = [(None, None), (5, 4), (8, None), (None, 3), (4, 6), (6, 2)][i]
+    row = mod.SLAMDPOTrainer.tokenize_row(feats, tok, mp, mc, False)  # the CLI passes the UnitTokeniser itself (preference_alignment_train.py:56-58)
+    g9.append({"features": feats, "max_prompt_length": mp, "max_completion_length": mc, "row": {k: list(v) for k, v in row.items()}})
+data["G9_dpo_rows"] = g9
+
 meta = {"config": cfg.to_dict(), "seed": SEED, "bias_std": BIAS_STD, "norm_jitter": JIT,
         "transformers": __import__("transformers").__version__, "torch": torch.__version__}
 data["meta"] = meta

@@ -122,3 +122,18 @@ def test_config_loader_matches_reference_hyperparameters():
     assert ta.per_device_train_batch_size == 8 and ta.max_steps == 7 and ta.bf16 is True
     assert cfg.tokeniser.params.load_fe is False and cfg.data.train_path == "/x/*.jsonl"
     assert load_config("train", ["model=default"]).model.context_len == 512
+
+
+def test_dpo_tokenize_row_matches_reference(golden_data):
+    """SLAMDPOTrainer.tokenize_row vs vectors produced by the reference's own function (stub trl base)."""
+    from oracle import slam_oracle as O
+    from slamkit_amd.trainer.slam_dpo_trainer import SLAMDPOTrainer
+    tok = _tok()
+    for g in golden_data["G9_dpo_rows"]:
+        row = SLAMDPOTrainer.tokenize_row(g["features"], tok, g["max_prompt_length"], g["max_completion_length"], False)
+        assert row == g["row"]
+        ids = {k: tok(g["features"][k], add_special_tokens=False)["input_ids"] for k in ("prompt", "chosen", "rejected")}
+        assert O.dpo_tokenize_row(ids["prompt"], ids["chosen"], ids["rejected"], max_prompt_length=g["max_prompt_length"],
+                                  max_completion_length=g["max_completion_length"]) == g["row"]
+        assert row["prompt_input_ids"][0] == 1 or g["max_prompt_length"] is not None
+        assert row["chosen_input_ids"][-1] == 1 or g["max_completion_length"] is not None
