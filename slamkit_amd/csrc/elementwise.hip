@@ -150,10 +150,14 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 16 columns x 16 row-slices, fixed order
+// out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 16 columns x 16 row-slices, fixed order.
+// blockIdx.y selects one of several equally shaped instances (per-layer partial slabs finished together).
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nb, int N,
-                                                            float* __restrict__ out, int accumulate) {
+                                                            float* __restrict__ out, int accumulate,
+                                                            size_t part_stride, size_t out_stride) {
   __shared__ float red[16][17];
+  part += (size_t)blockIdx.y * part_stride;
+  out += (size_t)blockIdx.y * out_stride;
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
@@ -525,8 +529,10 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 
 // dst[C][R] = src[R][C]^T, bf16, 64x64 tiles through LDS (R, C multiples of 64)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                             int R, int C) {
+                                                             int R, int C, size_t batch_stride) {
   __shared__ uint32_t t[64][33];  // 64 rows x 64 bf16 (+1 dword pad)
+  src += (size_t)blockIdx.z * batch_stride;  // same-shaped matrices at a constant stride (one per layer)
+  dst += (size_t)blockIdx.z * batch_stride;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -572,7 +578,14 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
   if ((H & 7) || H > MAXC * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   rmsnorm_bwd_kernel<<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);
-  colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate);
+  if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0);  // dw == null: caller finishes later
+  LAUNCH_RET();
+}
+// finish `count` equally shaped partial slabs in one launch: out[i] (+)= column sums of part[i]
+int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
+                       int accumulate, hipStream_t st) {
+  if (count <= 0) return 0;
+  colsum_finish_kernel<<<dim3((N + 15) / 16, count), 256, 0, st>>>(part, nb, N, out, accumulate, part_stride, out_stride);
   LAUNCH_RET();
 }
 
@@ -583,7 +596,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   int nb = colsum_blocks(M);
   dim3 grid((N / 8 + 255) / 256, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
-  colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate);
+  if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0);
   LAUNCH_RET();
 }
 
@@ -663,9 +676,9 @@ int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const fl
                                                      (float)eps, (float)wd, bc1, bc2s, zero_grad);
   LAUNCH_RET();
 }
-int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
-  if ((R & 63) || (C & 63)) return -1;
-  transpose_bf16_kernel<<<dim3(C / 64, R / 64), 256, 0, st>>>(src, dst, R, C);
+int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st) {
+  if ((R & 63) || (C & 63) || batch < 1) return -1;
+  transpose_bf16_kernel<<<dim3(C / 64, R / 64, batch), 256, 0, st>>>(src, dst, R, C, batch_stride);
   LAUNCH_RET();
 }
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st) {

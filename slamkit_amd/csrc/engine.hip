@@ -43,7 +43,7 @@ struct SlamEngine {
   SlamModelDesc d;
   int QKV;  // (nH + 2 nKV) * hd
   int64_t n_params;
-  int64_t off_embed, off_norm;
+  int64_t off_embed, off_norm, layer_stride = 0;
   std::vector<LayerOff> lo;
   std::vector<SlamTensorInfo> tensors;
   std::string err;
@@ -60,6 +60,8 @@ struct SlamEngine {
   std::vector<LayerAct> la;
   bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
+  float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
+  size_t ln_ps = 0, bias_ps = 0;
   int *seg_s, *seg_e, *attn_plan_buf;
 
   // last forward
@@ -147,6 +149,10 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   if (part2 > part) part = part2;
   if (part < 1024) part = 1024;
   e->part_ws = c.take<float>(part);
+  e->ln_ps = (size_t)rmsnorm_bwd_blocks((int)M) * H;
+  e->bias_ps = (size_t)colsum_blocks((int)M) * e->QKV;
+  e->ln_part = c.take<float>(e->ln_ps * 2 * L);
+  e->bias_part = c.take<float>(e->bias_ps * L);
   e->scal = c.take<float>(64);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -204,6 +210,7 @@ int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
     o.wgu = off;  add_tensor(e, p + "wgu", off, 2 * d.intermediate, d.hidden);
     o.wd = off;   add_tensor(e, p + "wd", off, d.hidden, d.intermediate);
   }
+  e->layer_stride = d.n_layers > 1 ? e->lo[1].ln1 - e->lo[0].ln1 : (off - e->lo[0].ln1);
   e->off_norm = off;
   add_tensor(e, "norm", off, d.hidden, 1);
   e->n_params = off;
@@ -235,14 +242,15 @@ int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream) {
   const bf16_t* P = h->params;
   bf16_t* Pt = h->params_t;
   const int H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
-  CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, VPAD, H, st));
-  for (int l = 0; l < d.n_layers; ++l) {
-    const LayerOff& o = h->lo[l];
-    CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, st));
-    CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, st));
-    CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, st));
-    CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, st));
-  }
+  CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, VPAD, H, 1, 0, st));
+  // every layer has the same shapes at a constant stride: one launch per weight kind, grid.z = layers
+  const LayerOff& o = h->lo[0];
+  const int L = d.n_layers;
+  const size_t ls = (size_t)h->layer_stride;
+  CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, L, ls, st));
+  CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, L, ls, st));
+  CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, L, ls, st));
+  CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, L, ls, st));
   return SLAM_OK;
 }
 int slam_bind_params_t(SlamEngine* h, void* params_t_bf16) {
@@ -376,6 +384,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
   int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
+  int fin_hi = L;                    // layers >= fin_hi have their norm/bias partial slabs finished
   for (int l = L - 1; l >= 0; --l) {
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
@@ -389,16 +398,25 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     }
     CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
-    CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, G + o.ln2, 1, h->part_ws, M, H, st));
+    CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
     CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->cosb, h->sinb, M,
                 nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
-    CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, G + o.bqkv, 1, h->part_ws, st));
+    CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
     CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
-    CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, G + o.ln1, 1, h->part_ws, M, H, st));
+    CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
+    if (l == 0 || (cb && ((L - l) % bl) == 0)) {
+      // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
+      const int cnt = fin_hi - l;
+      const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, 1, st));
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, 1, st));
+      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, 1, st));
+      fin_hi = l;
+    }
     if (cb && l > 0 && ((L - l) % bl) == 0) {
       cb(user, o.ln1, bucket_end - o.ln1);
       bucket_end = o.ln1;
