@@ -99,7 +99,7 @@ SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
 // Forward. grid (ceil(M/128), nH); wave w owns query rows q0+32w .. +31 (two 16-row fragments).
 // Stage = K D-image + V T-image (16 KB), 3-stage ring, 4 DMAs per lane per tile.
 constexpr int FWD_NST = 3;
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -176,9 +176,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     // two separately compiled bodies so the unmasked fast path carries no compare / select at all
     auto softmax_tile = [&](auto mk) {
       constexpr bool MASK = decltype(mk)::value;
+      // Deferred running max (threshold 8 in the exp2 domain, P <= 256): the running max of a row is
+      // only raised - with the cross-lane reduction, the exp of the correction and the rescale of O -
+      // when some element of the tile exceeds it by more than the threshold. The test is lane-local
+      // (each lane checks its own 16 scores against the shared max) and wave-uniform via a ballot, so
+      // the common tile has no shuffles and no dependent chain through LDS.
+      float mloc[2];
+      bool grow = false;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float mx = NEG_BIG;
         if constexpr (MASK) {
 #pragma unroll
           for (int f = 0; f < 4; ++f)
@@ -189,33 +195,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
               st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
             }
         }
+        float mx = NEG_BIG;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun[j], mx);
-        const float alpha = fast_exp2((mrun[j] - mnew) * c2);
-        mrun[j] = mnew;
-        const float mc = mnew * c2;
+        mloc[j] = mx;
+        grow |= (mx - mrun[j]) * c2 > 8.0f;
+      }
+      if (__any(grow)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float mx = mloc[j];
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float mnew = fmaxf(mrun[j], mx);
+          const float alpha = fast_exp2((mrun[j] - mnew) * c2);
+          mrun[j] = mnew;
+          lsum[j] *= alpha;
+#pragma unroll
+          for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float mc = mrun[j] * c2;
         float ps = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             // masked entries are NEG_BIG: exp2 underflows to 0 unless the whole row is still masked
-            // (mnew == NEG_BIG), which the explicit select handles
+            // (mrun == NEG_BIG), which the explicit select handles
             float e = fast_exp2(fmaf(st[f][j][r], c2, -mc));
             if constexpr (MASK) e = (st[f][j][r] <= 0.5f * NEG_BIG) ? 0.f : e;
             st[f][j][r] = e;
             ps += e;
           }
-        lsum[j] = lsum[j] * alpha + ps;
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+        lsum[j] += ps;
         pb[0][j] = pack_pair(st[0][j], st[1][j]);
         pb[1][j] = pack_pair(st[2][j], st[3][j]);
       }
@@ -254,8 +273,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
 // Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
-constexpr int DQ_NST = 3;
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+constexpr int DQ_NST = 2;
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < n; ++t) {
-    if (n - 1 - t >= 1) wait_vmcnt<6>();
+    if (DQ_NST >= 3 && n - 1 - t >= 1) wait_vmcnt<6>();
     else wait_vmcnt<0>();
     __syncthreads();
     if (t + DQ_NST - 1 < n) issue(t + DQ_NST - 1);

@@ -714,7 +714,10 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   splits = (M + per - 1) / per;
   GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
   const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
-  int e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
+  int e;
+  if (dma_ok && g_gemm_tn_dma == 2 && N % 256 == 0) e = launch<true, true, true, 2, 8, 256>(a, splits, st);
+  else if (dma_ok && g_gemm_tn_dma == 3 && N % 256 == 0) e = launch<true, true, true, 3, 8, 256>(a, splits, st);
+  else e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
   reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate);

@@ -32,11 +32,11 @@ def rb(*s):
 
 st = E.current_stream_ptr()
 print(f"{'op':28s} {'mode':>5s} {'us':>9s} {'TFLOP/s':>9s}")
-for name, (N, K) in {"qkv fwd": (1152, 896), "o fwd/dgrad": (896, 896), "gate_up fwd": (9728, 896),
+for name, (N, K) in {} if len(sys.argv) > 2 else {"qkv fwd": (1152, 896), "o fwd/dgrad": (896, 896), "gate_up fwd": (9728, 896),
                      "down fwd": (896, 4864), "qkv dgrad": (896, 1152), "down dgrad": (4864, 896),
                      "gate_up dgrad": (896, 9728)}.items():
     x, w, y = rb(M, K), rb(N, K), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for mode, gr in ((2, 1), (2, 4), (2, 8), (2, 16), (163, 1), (163, 4), (163, 8)):
+    for mode, gr in ((2, 4),):
         lib.slam_set_option(None, b"gemm_group_rows", gr)
         us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, mode, st))
         print(f"nt {name:25s} {mode:5d} gr={gr:2d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
@@ -46,8 +46,11 @@ for name, (N, K) in {"wqkv": (1152, 896), "wo": (896, 896), "wgu": (9728, 896), 
     ws = torch.empty(lib.slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device=dev)
     dw = torch.zeros(N, K, dtype=torch.float32, device=dev)
     ws = torch.empty(32 * N * K + 16, dtype=torch.float32, device=dev)
-    for sp in (0, 1, 2, 3, 4, 6, 8, 10, 12, 16):
-        lib.slam_set_option(None, b"gemm_tn_splits", sp)
-        us = timeit(lambda: lib.slam_op_gemm_tn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 1, M, N, K, ws.data_ptr(), st))
-        print(f"tn {name:25s} S={sp:3d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
+    for cfg in (1,):
+        lib.slam_set_option(None, b"gemm_tn_dma", cfg)
+        for sp in (0,):
+            lib.slam_set_option(None, b"gemm_tn_splits", sp)
+            us = timeit(lambda: lib.slam_op_gemm_tn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 1, M, N, K, ws.data_ptr(), st))
+            print(f"tn {name:20s} cfg={cfg} S={sp:3d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}")
     lib.slam_set_option(None, b"gemm_tn_splits", 0)
+    lib.slam_set_option(None, b"gemm_tn_dma", 1)
