@@ -40,9 +40,9 @@ typedef struct SlamModelDesc {
   int32_t hidden;        /* 896 */
   int32_t n_heads;       /* 14  */
   int32_t n_kv_heads;    /* 2   */
-  int32_t head_dim;      /* 64 (only 64 supported) */
+  int32_t head_dim;      /* 64 or 128 */
   int32_t intermediate;  /* 4864 */
-  int32_t vocab;         /* 502 (<= 512 supported; rows padded to 512 internally) */
+  int32_t vocab;         /* 502; embedding rows are padded to 512, or to a multiple of 128 beyond 512 */
   int32_t pad_token_id;  /* 0: nn.Embedding(padding_idx) gather-gradient suppression; -1 = none */
   float rms_eps;         /* 1e-6 */
   float rope_theta;      /* 10000 */
@@ -138,18 +138,23 @@ int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int 
 size_t slam_op_rmsnorm_bwd_workspace(int M, int H);
 int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                         float* dw, float* ws, int M, int H, slam_stream_t s);
-int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, const int64_t* position_ids, float theta,
-                 int backward, float* cos_sin_ws /* 2*M*32 floats */, slam_stream_t s);
+int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, int head_dim, const int64_t* position_ids, float theta,
+                 int backward, float* cos_sin_ws /* 2*M*(head_dim/2) floats */, slam_stream_t s);
 int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s);
 int slam_op_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, slam_stream_t s);
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
-                     slam_stream_t s);
-size_t slam_op_attn_bwd_workspace(int M, int nH);
+                     int head_dim, slam_stream_t s);
+size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim);
 int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
-                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, slam_stream_t s);
-int slam_op_cross_entropy(const void* logits /* bf16 [B*T][512] */, const int64_t* labels, double num_items,
-                          void* dlogits, float* row_loss, float* scratch2 /* {denom, loss} */, int B, int T, int V,
-                          slam_stream_t s);
+                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, int head_dim,
+                     slam_stream_t s);
+int slam_op_cross_entropy(const void* logits /* bf16 [B*T][Vp] */, const int64_t* labels, double num_items,
+                          void* dlogits, float* row_loss, float* scratch2 /* {denom, loss} */, int B, int T,
+                          int Vp /* padded row length: 512, or a multiple of 8 beyond */, int V, slam_stream_t s);
+/* gather-side embedding gradient for vocabularies beyond 512: dE[ids[m]] += dh[m], token order (deterministic) */
+size_t slam_op_embed_bwd_workspace(int M, int Vp);
+int slam_op_embed_bwd(const int64_t* ids, const void* dh /* bf16 [M][H] */, float* dE /* fp32 [Vp][H] */, int M, int H,
+                      int Vp, int V, int pad_id, void* ws, slam_stream_t s);
 
 #ifdef __cplusplus
 }

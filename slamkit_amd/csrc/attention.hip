@@ -1,5 +1,5 @@
-// Causal grouped-query flash attention (head_dim 64) for gfx950, forward + backward, over a packed
-// token axis: row m of qkv[M][(nH+2nKV)*64] attends rows seg_start[m] <= j <= m. Dense [B,T]
+// Causal grouped-query flash attention (head_dim 64 or 128) for gfx950, forward + backward, over a packed
+// token axis: row m of qkv[M][(nH+2nKV)*D] attends rows seg_start[m] <= j <= m. Dense [B,T]
 // batches are the special case seg_start = (m/T)*T; right padding needs no key mask (a real
 // query never sees a later pad key under the causal mask); packed batches pass the segment
 // starts derived from position_ids == 0 (flattening collator, hf_dataset.py:61-62).
@@ -15,7 +15,10 @@
 //    stages, ONE barrier per tile, no register staging): a "D image" (16-B chunk swizzle, read
 //    with ds_read_b128 when the contraction runs along head_dim) and/or a "T image" (32-B block
 //    swizzle, read with ds_read_b64_tr_b16 when the contraction runs along the rows);
-//  * per-element masking only on tiles that touch the diagonal, a segment start or the tail.
+//  * per-element masking only on tiles that touch the diagonal, a segment start or the tail;
+//  * head_dim D = 64*ND: every operand tile is ND side-by-side 64x64 sub-images (columns 64*dh..),
+//    each with the 64-column layouts above, so the D = 128 kernels are the same code with one more
+//    loop level (Qwen2.5-1.5B-shaped models).
 #include <type_traits>
 
 #include "common.h"
@@ -28,15 +31,15 @@ constexpr float NEG_BIG = -1.0e30f;
 
 struct AttnArgs {
   const bf16_t* qkv;   // [M][ldq]
-  bf16_t* o;           // [M][nH*64]            (fwd out / bwd in)
-  const bf16_t* d_o;   // [M][nH*64]
+  bf16_t* o;           // [M][nH*D]             (fwd out / bwd in)
+  const bf16_t* d_o;   // [M][nH*D]
   bf16_t* dqkv;        // [M][ldq]
   float* lse2;         // [nH][M]  log2-domain logsumexp of scaled scores
   float* dsum;         // [nH][M]  rowsum(dO*O)
-  float* dkv_part;     // [2][nH][M][64] fp32 per-q-head dK / dV partials
+  float* dkv_part;     // [2][nH][M][D] fp32 per-q-head dK / dV partials
   const int* seg_start;  // [M]
   const int* seg_end;    // [M]
-  const float* rope_cs;  // nullable fp32 [M][32]: fold the transpose RoPE rotation into the dq / dk stores
+  const float* rope_cs;  // nullable fp32 [M][D/2]: fold the transpose RoPE rotation into the dq / dk stores
   const float* rope_sn;
   const int* perm;     // nullable: block rank -> q/key tile index, heaviest tiles first (attn_plan_kernel)
   int M, nH, nKV, ldq;
@@ -98,8 +101,15 @@ SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
 // ------------------------------------------------------------------------------------------
 // Forward. grid (ceil(M/128), nH); wave w owns query rows q0+32w .. +31 (two 16-row fragments).
 // Stage = K D-image + V T-image (16 KB), 3-stage ring, 4 DMAs per lane per tile.
-constexpr int FWD_NST = 3;
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
+template <int ND>
+struct FwdCfg {
+  static constexpr int NST = ND == 1 ? 3 : 2;   // ring depth: 48 KB (3 blocks/CU) or 64 KB (2 blocks/CU)
+  static constexpr int STAGE = 2 * ND * IMG;
+  static constexpr int OCC = ND == 1 ? 3 : 2;
+};
+template <int ND>
+__global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int FWD_NST = FwdCfg<ND>::NST, STG = FwdCfg<ND>::STAGE, D = 64 * ND;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -108,9 +118,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   const int q0 = (p.perm ? p.perm[slot] : slot) * 128;
   const int qw0 = q0 + wave * 32;
   const int M = p.M, ld = p.ldq;
-  const bf16_t* Qb = p.qkv + h * 64;
-  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
-  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
+  const bf16_t* Qb = p.qkv + h * D;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
   const float c2 = p.scale * 1.44269504088896340736f;
   const uint32_t lds0 = lds_addr(smem);
 
@@ -121,16 +131,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   offD.init(ld, tid); offT.init(ld, tid);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t % FWD_NST) * 2 * IMG);
-    dma_tile64<false>(Kb, offD, (kt_begin + t) * 64, M, wv, st);
-    dma_tile64<true>(Vb, offT, (kt_begin + t) * 64, M, wv, st + IMG);
+    const uint32_t st = lds0 + (uint32_t)((t % FWD_NST) * STG);
+#pragma unroll
+    for (int dh = 0; dh < ND; ++dh) {
+      dma_tile64<false>(Kb + dh * 64, offD, (kt_begin + t) * 64, M, wv, st + dh * IMG);
+      dma_tile64<true>(Vb + dh * 64, offT, (kt_begin + t) * 64, M, wv, st + (ND + dh) * IMG);
+    }
   };
 #pragma unroll
   for (int s = 0; s < FWD_NST - 1; ++s)
     if (s < n) issue(s);
 
   int qrow[2], segs[2];
-  uint4 qf[2][2];
+  uint4 qf[2][2 * ND];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int q = qw0 + j * 16 + l15;
@@ -138,24 +151,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     int qc = q < M ? q : M - 1;
     segs[j] = p.seg_start[qc];
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2 * ND; ++ds)
       qf[j][ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
   }
   const int segmax_w = p.seg_start[min(qw0 + 31, M - 1)];  // latest segment start among the wave's rows
-  f32x4_t ot[4][2];
+  f32x4_t ot[4 * ND][2];
 #pragma unroll
-  for (int fd = 0; fd < 4; ++fd)
+  for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
     for (int j = 0; j < 2; ++j) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float mrun[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};  // running max in raw-score units
 
   for (int t = 0; t < n; ++t) {
-    if (n - 1 - t >= 1) wait_vmcnt<4>();  // tile t landed once at most one later tile (4 DMAs) is in flight
+    // 3-deep ring: tile t landed once at most one later tile (4 DMAs per sub-image pair) is in flight
+    if (FWD_NST >= 3 && n - 1 - t >= 1) wait_vmcnt<4 * ND>();
     else wait_vmcnt<0>();
     __syncthreads();
     if (t + FWD_NST - 1 < n) issue(t + FWD_NST - 1);
-    const char* Ks = smem + (t % FWD_NST) * 2 * IMG;
-    const char* Vs = Ks + IMG;
+    const char* Ks = smem + (t % FWD_NST) * STG;
+    const char* Vs = Ks + ND * IMG;
     const int key0 = (kt_begin + t) * 64;
     if (key0 > qw0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
     f32x4_t st[4][2];
@@ -164,10 +178,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2 * ND; ++ds)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        uint4 kf = frag_direct(Ks, f, l15, g, ds);
+        uint4 kf = frag_direct(Ks + (ds >> 1) * IMG, f, l15, g, ds & 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
       }
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
           mrun[j] = mnew;
           lsum[j] *= alpha;
 #pragma unroll
-          for (int fd = 0; fd < 4; ++fd)
+          for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
         }
@@ -244,8 +258,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int fd = 0; fd < 4; ++fd) {
-        uint4 vf = frag_tr(Vs, fd, l15, g, t2);
+      for (int fd = 0; fd < 4 * ND; ++fd) {
+        uint4 vf = frag_tr(Vs + (fd >> 2) * IMG, fd & 3, l15, g, t2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf, pb[t2][j], ot[fd][j]);
       }
@@ -259,11 +273,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     if (q < M) {
       const float inv = 1.f / l;
 #pragma unroll
-      for (int fd = 0; fd < 4; ++fd) {
+      for (int fd = 0; fd < 4 * ND; ++fd) {
         uint2 o;
         o.x = pack_bf16x2(ot[fd][j][0] * inv, ot[fd][j][1] * inv);
         o.y = pack_bf16x2(ot[fd][j][2] * inv, ot[fd][j][3] * inv);
-        *reinterpret_cast<uint2*>(p.o + (size_t)q * (p.nH * 64) + h * 64 + fd * 16 + g * 4) = o;
+        *reinterpret_cast<uint2*>(p.o + (size_t)q * (p.nH * D) + h * D + fd * 16 + g * 4) = o;
       }
       if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = mrun[j] * c2 + log2f(l);
     }
@@ -274,7 +288,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
 // Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
 constexpr int DQ_NST = 2;
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
+template <int ND>
+__global__ __launch_bounds__(256, ND == 1 ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, STG = 3 * ND * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -283,9 +299,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
   const int q0 = (p.perm ? p.perm[slot] : slot) * 64;
   const int qw0 = q0 + wave * 16;
   const int M = p.M, ld = p.ldq;
-  const bf16_t* Qb = p.qkv + h * 64;
-  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
-  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
+  const bf16_t* Qb = p.qkv + h * D;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
   const float c2 = p.scale * 1.44269504088896340736f;
   const uint32_t lds0 = lds_addr(smem);
 
@@ -296,11 +312,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
   offD.init(ld, tid); offT.init(ld, tid);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t % DQ_NST) * 3 * IMG);
+    const uint32_t st = lds0 + (uint32_t)((t % DQ_NST) * STG);
     const int r0 = (kt_begin + t) * 64;
-    dma_tile64<false>(Kb, offD, r0, M, wv, st);
-    dma_tile64<true>(Kb, offT, r0, M, wv, st + IMG);
-    dma_tile64<false>(Vb, offD, r0, M, wv, st + 2 * IMG);
+#pragma unroll
+    for (int dh = 0; dh < ND; ++dh) {
+      dma_tile64<false>(Kb + dh * 64, offD, r0, M, wv, st + dh * IMG);
+      dma_tile64<true>(Kb + dh * 64, offT, r0, M, wv, st + (ND + dh) * IMG);
+      dma_tile64<false>(Vb + dh * 64, offD, r0, M, wv, st + (2 * ND + dh) * IMG);
+    }
   };
 #pragma unroll
   for (int s = 0; s < DQ_NST - 1; ++s)
@@ -311,13 +330,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
   const int seg = p.seg_start[qc];
   const float lse = p.lse2[(size_t)h * M + qc];
   const int segmax_w = p.seg_start[min(qw0 + 15, M - 1)];
-  uint4 qf[2], dof[2];
-  float dsm = 0.f;  // D[q] = sum_d dO[q][d] * O[q][d]: each lane owns 16 of the 64 d's, 4 lanes per row
+  uint4 qf[2 * ND], dof[2 * ND];
+  float dsm = 0.f;  // D[q] = sum_d dO[q][d] * O[q][d]: each lane owns a quarter of the d's, 4 lanes per row
 #pragma unroll
-  for (int ds = 0; ds < 2; ++ds) {
+  for (int ds = 0; ds < 2 * ND; ++ds) {
     qf[ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
-    dof[ds] = *reinterpret_cast<const uint4*>(p.d_o + (size_t)qc * p.nH * 64 + h * 64 + g * 8 + 32 * ds);
-    uint4 of = *reinterpret_cast<const uint4*>(p.o + (size_t)qc * p.nH * 64 + h * 64 + g * 8 + 32 * ds);
+    dof[ds] = *reinterpret_cast<const uint4*>(p.d_o + (size_t)qc * p.nH * D + h * D + g * 8 + 32 * ds);
+    uint4 of = *reinterpret_cast<const uint4*>(p.o + (size_t)qc * p.nH * D + h * D + g * 8 + 32 * ds);
     float x[8], y[8];
     unpack_bf16x8(dof[ds], x);
     unpack_bf16x8(of, y);
@@ -327,29 +346,29 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
   dsm += __shfl_xor(dsm, 16, 64);
   dsm += __shfl_xor(dsm, 32, 64);
   if (g == 0 && q < M) p.dsum[(size_t)h * M + q] = dsm;  // consumed by the dK/dV kernel (launched after this one)
-  f32x4_t dq[4];
+  f32x4_t dq[4 * ND];
 #pragma unroll
-  for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int fd = 0; fd < 4 * ND; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < n; ++t) {
     if (DQ_NST >= 3 && n - 1 - t >= 1) wait_vmcnt<6>();
     else wait_vmcnt<0>();
     __syncthreads();
     if (t + DQ_NST - 1 < n) issue(t + DQ_NST - 1);
-    const char* Ks = smem + (t % DQ_NST) * 3 * IMG;
-    const char* Kt = Ks + IMG;
-    const char* Vs = Ks + 2 * IMG;
+    const char* Ks = smem + (t % DQ_NST) * STG;
+    const char* Kt = Ks + ND * IMG;
+    const char* Vs = Ks + 2 * ND * IMG;
     const int key0 = (kt_begin + t) * 64;
     if (key0 > qw0 + 15) continue;
     f32x4_t st[4], dp[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { st[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[f] = st[f]; }
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2 * ND; ++ds)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        st[f] = mfma16(frag_direct(Ks, f, l15, g, ds), qf[ds], st[f]);
-        dp[f] = mfma16(frag_direct(Vs, f, l15, g, ds), dof[ds], dp[f]);
+        st[f] = mfma16(frag_direct(Ks + (ds >> 1) * IMG, f, l15, g, ds & 1), qf[ds], st[f]);
+        dp[f] = mfma16(frag_direct(Vs + (ds >> 1) * IMG, f, l15, g, ds & 1), dof[ds], dp[f]);
       }
     const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + 15 >= M);
 #pragma unroll
@@ -368,33 +387,33 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int fd = 0; fd < 4; ++fd) dq[fd] = mfma16(frag_tr(Kt, fd, l15, g, t2), dsb[t2], dq[fd]);
+      for (int fd = 0; fd < 4 * ND; ++fd) dq[fd] = mfma16(frag_tr(Kt + (fd >> 2) * IMG, fd & 3, l15, g, t2), dsb[t2], dq[fd]);
   }
   if (q < M) {
 #pragma unroll
-    for (int fd = 0; fd < 4; ++fd)
+    for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dq[fd][r] *= p.scale;
-    if (p.rope_cs) {  // transpose rotation: d(pre-RoPE q); fragments fd and fd+2 hold d and d+32
+    if (p.rope_cs) {  // transpose rotation: d(pre-RoPE q); fragments fd and fd + 2ND hold d and d + D/2
 #pragma unroll
-      for (int fd = 0; fd < 2; ++fd) {
-        const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)q * 32 + fd * 16 + g * 4);
-        const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)q * 32 + fd * 16 + g * 4);
+      for (int fd = 0; fd < 2 * ND; ++fd) {
+        const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)q * (D / 2) + fd * 16 + g * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)q * (D / 2) + fd * 16 + g * 4);
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a = dq[fd][r], b = dq[fd + 2][r];
+          float a = dq[fd][r], b = dq[fd + 2 * ND][r];
           dq[fd][r] = a * cc[r] + b * ss[r];
-          dq[fd + 2][r] = b * cc[r] - a * ss[r];
+          dq[fd + 2 * ND][r] = b * cc[r] - a * ss[r];
         }
       }
     }
 #pragma unroll
-    for (int fd = 0; fd < 4; ++fd) {
+    for (int fd = 0; fd < 4 * ND; ++fd) {
       uint2 o;
       o.x = pack_bf16x2(dq[fd][0], dq[fd][1]);
       o.y = pack_bf16x2(dq[fd][2], dq[fd][3]);
-      *reinterpret_cast<uint2*>(p.dqkv + (size_t)q * ld + h * 64 + fd * 16 + g * 4) = o;
+      *reinterpret_cast<uint2*>(p.dqkv + (size_t)q * ld + h * D + fd * 16 + g * 4) = o;
     }
   }
 }
@@ -405,19 +424,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 // Stage = Q D/T images + dO D/T images (32 KB) + lse2 / dsum / seg_start of the 64 query rows
 // (3 x 256 B, by 4-byte LDS-DMA), 2-stage ring, 9 DMAs per lane per tile.
 constexpr int DKV_NST = 2;
-constexpr int DKV_STAGE = 4 * IMG + 1024;
+template <int ND>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, DKV_STAGE = 4 * ND * IMG + 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x % p.nH, kvh = h / (p.nH / p.nKV);
   const int slot = blockIdx.x / p.nH;
   const int k0 = (p.perm ? p.perm[slot] : slot) * 64;
-  const int M = p.M, ld = p.ldq, ldo = p.nH * 64;
-  const bf16_t* Qb = p.qkv + h * 64;
-  const bf16_t* Kb = p.qkv + (p.nH + kvh) * 64;
-  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * 64;
-  const bf16_t* dOb = p.d_o + h * 64;
+  const int M = p.M, ld = p.ldq, ldo = p.nH * D;
+  const bf16_t* Qb = p.qkv + h * D;
+  const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
+  const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
+  const bf16_t* dOb = p.d_o + h * D;
   const float c2 = p.scale * 1.44269504088896340736f;
   const uint32_t lds0 = lds_addr(smem);
 
@@ -430,40 +450,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   auto issue = [&](int t) {
     const uint32_t st = lds0 + (uint32_t)((t % DKV_NST) * DKV_STAGE);
     const int r0 = (qt_begin + t) * 64;
-    dma_tile64<false>(Qb, qD, r0, M, wv, st);
-    dma_tile64<true>(Qb, qT, r0, M, wv, st + IMG);
-    dma_tile64<false>(dOb, oD, r0, M, wv, st + 2 * IMG);
-    dma_tile64<true>(dOb, oT, r0, M, wv, st + 3 * IMG);
+#pragma unroll
+    for (int dh = 0; dh < ND; ++dh) {
+      dma_tile64<false>(Qb + dh * 64, qD, r0, M, wv, st + dh * IMG);
+      dma_tile64<true>(Qb + dh * 64, qT, r0, M, wv, st + (ND + dh) * IMG);
+      dma_tile64<false>(dOb + dh * 64, oD, r0, M, wv, st + (2 * ND + dh) * IMG);
+      dma_tile64<true>(dOb + dh * 64, oT, r0, M, wv, st + (3 * ND + dh) * IMG);
+    }
     // per-row scalars: wave 0 -> lse2, 1 -> dsum, 2 -> seg_start, 3 -> spare slot (keeps the DMA count uniform)
     const int row = min(r0 + lane, M - 1);
     const void* src = wv == 0 ? (const void*)(p.lse2 + (size_t)h * M + row)
                     : wv == 1 ? (const void*)(p.dsum + (size_t)h * M + row)
                               : (const void*)(p.seg_start + row);
-    glds4(src, __builtin_amdgcn_readfirstlane(st + 4 * IMG + (uint32_t)wv * 256u));
+    glds4(src, __builtin_amdgcn_readfirstlane(st + 4 * ND * IMG + (uint32_t)wv * 256u));
   };
   if (n > 0) issue(0);
 
   const int key = k0 + wave * 16 + l15;
   const int kc = key < M ? key : M - 1;
-  uint4 kf[2], vf[2];
+  uint4 kf[2 * ND], vf[2 * ND];
 #pragma unroll
-  for (int ds = 0; ds < 2; ++ds) {
+  for (int ds = 0; ds < 2 * ND; ++ds) {
     kf[ds] = *reinterpret_cast<const uint4*>(Kb + (size_t)kc * ld + g * 8 + 32 * ds);
     vf[ds] = *reinterpret_cast<const uint4*>(Vb + (size_t)kc * ld + g * 8 + 32 * ds);
   }
-  f32x4_t dk[4], dv[4];
+  f32x4_t dk[4 * ND], dv[4 * ND];
 #pragma unroll
-  for (int fd = 0; fd < 4; ++fd) { dk[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[fd] = dk[fd]; }
+  for (int fd = 0; fd < 4 * ND; ++fd) { dk[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[fd] = dk[fd]; }
 
   for (int t = 0; t < n; ++t) {
     wait_vmcnt<0>();
     __syncthreads();
     if (t + 1 < n) issue(t + 1);
     const char* Qs = smem + (t % DKV_NST) * DKV_STAGE;
-    const char* Qt = Qs + IMG;
-    const char* dOs = Qs + 2 * IMG;
-    const char* dOt = Qs + 3 * IMG;
-    const float* lse_s = reinterpret_cast<const float*>(Qs + 4 * IMG);
+    const char* Qt = Qs + ND * IMG;
+    const char* dOs = Qs + 2 * ND * IMG;
+    const char* dOt = Qs + 3 * ND * IMG;
+    const float* lse_s = reinterpret_cast<const float*>(Qs + 4 * ND * IMG);
     const float* dsm_s = lse_s + 64;
     const int* seg_s = reinterpret_cast<const int*>(lse_s + 128);
     const int qbase = (qt_begin + t) * 64;
@@ -473,11 +496,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) { s[jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[jq] = s[jq]; }
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < 2 * ND; ++ds)
 #pragma unroll
       for (int jq = 0; jq < 4; ++jq) {
-        s[jq] = mfma16(frag_direct(Qs, jq, l15, g, ds), kf[ds], s[jq]);
-        dp[jq] = mfma16(frag_direct(dOs, jq, l15, g, ds), vf[ds], dp[jq]);
+        s[jq] = mfma16(frag_direct(Qs + (ds >> 1) * IMG, jq, l15, g, ds & 1), kf[ds], s[jq]);
+        dp[jq] = mfma16(frag_direct(dOs + (ds >> 1) * IMG, jq, l15, g, ds & 1), vf[ds], dp[jq]);
       }
     // lane holds (q = qbase + jq*16 + 4g + r, key); mask only on diagonal / segment-boundary / tail tiles
     const bool need_mask = (kw0 + 15 > qbase) || (kw0 < seg_s[63]) || (qbase + 63 >= M);
@@ -505,16 +528,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int fd = 0; fd < 4; ++fd) {
-        dv[fd] = mfma16(frag_tr(dOt, fd, l15, g, t2), pb[t2], dv[fd]);
-        dk[fd] = mfma16(frag_tr(Qt, fd, l15, g, t2), dsb[t2], dk[fd]);
+      for (int fd = 0; fd < 4 * ND; ++fd) {
+        dv[fd] = mfma16(frag_tr(dOt + (fd >> 2) * IMG, fd & 3, l15, g, t2), pb[t2], dv[fd]);
+        dk[fd] = mfma16(frag_tr(Qt + (fd >> 2) * IMG, fd & 3, l15, g, t2), dsb[t2], dk[fd]);
       }
   }
   if (key < M) {
-    float* dkp = p.dkv_part + ((size_t)h * M + key) * 64;
-    float* dvp = p.dkv_part + ((size_t)(p.nH + h) * M + key) * 64;
+    float* dkp = p.dkv_part + ((size_t)h * M + key) * D;
+    float* dvp = p.dkv_part + ((size_t)(p.nH + h) * M + key) * D;
 #pragma unroll
-    for (int fd = 0; fd < 4; ++fd) {
+    for (int fd = 0; fd < 4 * ND; ++fd) {
       *reinterpret_cast<float4*>(dkp + fd * 16 + g * 4) =
           make_float4(dk[fd][0] * p.scale, dk[fd][1] * p.scale, dk[fd][2] * p.scale, dk[fd][3] * p.scale);
       *reinterpret_cast<float4*>(dvp + fd * 16 + g * 4) = make_float4(dv[fd][0], dv[fd][1], dv[fd][2], dv[fd][3]);
@@ -523,28 +546,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // dqkv[m][K head kvh / V head kvh] = bf16( sum over the group's query heads of the partials ); a thread
-// owns d = 4c..4c+3 and its rotate-half partner d+32, so dK can be rotated back in the same pass.
+// owns d = 4c..4c+3 and its rotate-half partner d + D/2, so dK can be rotated back in the same pass.
+template <int ND>
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p) {
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (which, m, kvh, c < 8)
+  constexpr int D = 64 * ND, HALF = D / 2, CPR = D / 8;  // CPR threads per (m, kv head)
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (which, m, kvh, c < CPR)
   const int grp = p.nH / p.nKV;
-  size_t total = (size_t)2 * p.M * p.nKV * 8;
+  size_t total = (size_t)2 * p.M * p.nKV * CPR;
   if (idx >= total) return;
-  int c = idx & 7;
-  size_t r = idx >> 3;
+  int c = idx % CPR;
+  size_t r = idx / CPR;
   int kvh = r % p.nKV; r /= p.nKV;
   int m = r % p.M;
   int which = (int)(r / p.M);
   float4 a = make_float4(0, 0, 0, 0), b = a;
   for (int i = 0; i < grp; ++i) {
     int h = kvh * grp + i;
-    const float* src = p.dkv_part + (((size_t)which * p.nH + h) * p.M + m) * 64 + c * 4;
-    float4 v = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 32);
+    const float* src = p.dkv_part + (((size_t)which * p.nH + h) * p.M + m) * D + c * 4;
+    float4 v = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + HALF);
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
   }
   if (which == 0 && p.rope_cs) {
-    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)m * 32 + c * 4);
-    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)m * 32 + c * 4);
+    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cs + (size_t)m * HALF + c * 4);
+    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sn + (size_t)m * HALF + c * 4);
     float4 x = a, y = b;
     a = make_float4(x.x * c4.x + y.x * s4.x, x.y * c4.y + y.y * s4.y, x.z * c4.z + y.z * s4.z, x.w * c4.w + y.w * s4.w);
     b = make_float4(y.x * c4.x - x.x * s4.x, y.y * c4.y - x.y * s4.y, y.z * c4.z - x.z * s4.z, y.w * c4.w - x.w * s4.w);
@@ -552,9 +577,9 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p) {
   uint2 o1, o2;
   o1.x = pack_bf16x2(a.x, a.y); o1.y = pack_bf16x2(a.z, a.w);
   o2.x = pack_bf16x2(b.x, b.y); o2.y = pack_bf16x2(b.z, b.w);
-  int col = (p.nH + (which ? p.nKV : 0) + kvh) * 64 + c * 4;
+  int col = (p.nH + (which ? p.nKV : 0) + kvh) * D + c * 4;
   *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col) = o1;
-  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col + 32) = o2;
+  *reinterpret_cast<uint2*>(p.dqkv + (size_t)m * p.ldq + col + HALF) = o2;
 }
 
 // Longest-processing-time-first block order. Causal tiles differ 1:16 in work; in launch order the
@@ -597,52 +622,67 @@ int attn_plan(const int* seg_start, const int* seg_end, int M, int* plan, hipStr
   return (int)hipGetLastError();
 }
 
+template <int ND>
 static int set_lds_attrs() {
   static bool done = false;
   if (done) return 0;
   hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NST * 2 * IMG);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          FwdCfg<ND>::NST * FwdCfg<ND>::STAGE);
   if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NST * 3 * IMG);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          DQ_NST * 3 * ND * IMG);
   if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NST * DKV_STAGE);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          DKV_NST * (4 * ND * IMG + 1024));
   if (e != hipSuccess) return (int)e;
   done = true;
   return 0;
 }
 
-int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH,
-             int nKV, int head_dim, hipStream_t st) {
-  if (head_dim != 64 || nH % nKV) return -1;
-  AttnArgs a{};
-  a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start; a.perm = plan;
-  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
-  if (int e = set_lds_attrs()) return e;
-  attn_fwd_kernel<<<((M + 127) / 128) * nH, 256, FWD_NST * 2 * IMG, st>>>(a);
+template <int ND>
+static int attn_fwd_nd(AttnArgs a, hipStream_t st) {
+  if (int e = set_lds_attrs<ND>()) return e;
+  attn_fwd_kernel<ND><<<((a.M + 127) / 128) * a.nH, 256, FwdCfg<ND>::NST * FwdCfg<ND>::STAGE, st>>>(a);
   return (int)hipGetLastError();
 }
 
-size_t attn_bwd_workspace_bytes(int M, int nH) { return (size_t)2 * nH * M * 64 * sizeof(float); }
+template <int ND>
+static int attn_bwd_nd(AttnArgs a, const int* plan, hipStream_t st) {
+  if (int e = set_lds_attrs<ND>()) return e;
+  const int M = a.M, nH = a.nH;
+  const int nf = (M + 127) / 128, nq = (M + 63) / 64;
+  a.perm = plan ? plan + nf : nullptr;
+  attn_bwd_dq_kernel<ND><<<nq * nH, 256, DQ_NST * 3 * ND * IMG, st>>>(a);
+  a.perm = plan ? plan + nf + nq : nullptr;
+  attn_bwd_dkv_kernel<ND><<<nq * nH, 256, DKV_NST * (4 * ND * IMG + 1024), st>>>(a);
+  size_t total = (size_t)2 * M * a.nKV * (8 * ND);
+  attn_dkv_reduce_kernel<ND><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH,
+             int nKV, int head_dim, hipStream_t st) {
+  if ((head_dim != 64 && head_dim != 128) || nH % nKV) return -1;
+  AttnArgs a{};
+  a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start; a.perm = plan;
+  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);
+  return head_dim == 64 ? attn_fwd_nd<1>(a, st) : attn_fwd_nd<2>(a, st);
+}
+
+size_t attn_bwd_workspace_bytes(int M, int nH, int head_dim) { return (size_t)2 * nH * M * head_dim * sizeof(float); }
 
 int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum,
              bf16_t* dqkv, float* dkv_part, const int* seg_start, const int* seg_end, const int* plan,
              const float* rope_cs, const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st) {
-  if (head_dim != 64 || nH % nKV) return -1;
+  if ((head_dim != 64 && head_dim != 128) || nH % nKV) return -1;
   AttnArgs a{};
   a.qkv = qkv; a.o = const_cast<bf16_t*>(o); a.d_o = d_o; a.dqkv = dqkv;
   a.lse2 = const_cast<float*>(lse2); a.dsum = dsum; a.dkv_part = dkv_part;
   a.seg_start = seg_start; a.seg_end = seg_end;
   a.rope_cs = rope_cs; a.rope_sn = rope_sn;
-  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * 64; a.scale = 0.125f;
-  if (int e = set_lds_attrs()) return e;
-  const int nf = (M + 127) / 128, nq = (M + 63) / 64;
-  a.perm = plan ? plan + nf : nullptr;
-  attn_bwd_dq_kernel<<<nq * nH, 256, DQ_NST * 3 * IMG, st>>>(a);
-  a.perm = plan ? plan + nf + nq : nullptr;
-  attn_bwd_dkv_kernel<<<nq * nH, 256, DKV_NST * DKV_STAGE, st>>>(a);
-  size_t total = (size_t)2 * M * nKV * 8;
-  attn_dkv_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
-  return (int)hipGetLastError();
+  a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);
+  return head_dim == 64 ? attn_bwd_nd<1>(a, plan, st) : attn_bwd_nd<2>(a, plan, st);
 }
 
 }  // namespace slam

@@ -189,24 +189,25 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, int M, int T,
   sn[i] = s;
 }
 
-// In-place rotate-half RoPE on the first `nrot` heads of each row of qkv [M][ld] (head_dim 64).
-// dir = +1 forward, -1 backward (transpose rotation).
-__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, int M, int nrot,
+// In-place rotate-half RoPE on the first `nrot` heads of each row of qkv [M][ld] (head_dim hd, a
+// multiple of 16). dir = +1 forward, -1 backward (transpose rotation).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, int M, int nrot, int hd,
                                                    const float* __restrict__ cs, const float* __restrict__ sn,
                                                    float dir) {
-  // one thread: 8 low-half elems + their 8 high-half partners of one head; 4 threads per head
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  int per_row = nrot * 4;
-  if (idx >= M * per_row) return;
-  int m = idx / per_row, r = idx % per_row;
-  int head = r >> 2, part = r & 3;
-  bf16_t* base = qkv + (size_t)m * ld + head * 64 + part * 8;
-  uint4 lo = *reinterpret_cast<uint4*>(base), hi = *reinterpret_cast<uint4*>(base + 32);
+  // one thread: 8 low-half elems + their 8 high-half partners of one head; hd/16 threads per head
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int tph = hd >> 4, half = hd >> 1;
+  int per_row = nrot * tph;
+  if (idx >= (size_t)M * per_row) return;
+  int m = (int)(idx / per_row), r = (int)(idx % per_row);
+  int head = r / tph, part = r % tph;
+  bf16_t* base = qkv + (size_t)m * ld + head * hd + part * 8;
+  uint4 lo = *reinterpret_cast<uint4*>(base), hi = *reinterpret_cast<uint4*>(base + half);
   float a[8], b[8], c[8], s[8];
   unpack_bf16x8(lo, a);
   unpack_bf16x8(hi, b);
-  const float4* cp = reinterpret_cast<const float4*>(cs + (size_t)m * 32 + part * 8);
-  const float4* sp = reinterpret_cast<const float4*>(sn + (size_t)m * 32 + part * 8);
+  const float4* cp = reinterpret_cast<const float4*>(cs + (size_t)m * half + part * 8);
+  const float4* sp = reinterpret_cast<const float4*>(sn + (size_t)m * half + part * 8);
   *reinterpret_cast<float4*>(c) = cp[0]; *reinterpret_cast<float4*>(c + 4) = cp[1];
   *reinterpret_cast<float4*>(s) = sp[0]; *reinterpret_cast<float4*>(s + 4) = sp[1];
   float o1[8], o2[8];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int
     o2[j] = b[j] * c[j] + a[j] * sj;
   }
   *reinterpret_cast<uint4*>(base) = pack_bf16x8(o1);
-  *reinterpret_cast<uint4*>(base + 32) = pack_bf16x8(o2);
+  *reinterpret_cast<uint4*>(base + half) = pack_bf16x8(o2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -374,6 +375,146 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
       o[j] = pj * sc;
     }
     *dl = pack_bf16x8(o);
+  }
+}
+
+// Large vocabulary (Vp > 512, a multiple of 8): one 256-thread block per row, two passes over the
+// row (online max / sum, then the gradient); the second read hits L2 (a 152k-column row is 300 KB).
+// Algorithmic traffic: 2 B/logit read + 2 B/logit written.
+__global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ logits,
+                                                     const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
+                                                     float* __restrict__ row_loss, int B, int T, int Vp, int V) {
+  __shared__ float red_m[4], red_s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x;
+  const int t = m % T;
+  const int64_t tgt = (t < T - 1) ? labels[m + 1] : -100;
+  const bool valid = (tgt >= 0 && tgt < V);
+  const int nch = Vp >> 3;
+  const uint4* lr = reinterpret_cast<const uint4*>(logits + (size_t)m * Vp);
+  uint4* dl = dlogits ? reinterpret_cast<uint4*>(dlogits + (size_t)m * Vp) : nullptr;
+  if (!valid) {  // block-uniform
+    if (dl)
+      for (int c = tid; c < nch; c += 256) dl[c] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) row_loss[m] = 0.f;
+    return;
+  }
+  float mx = -3.0e38f, sm = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    float f[8];
+    unpack_bf16x8(lr[c], f);
+    float cm = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (c * 8 + j >= V) f[j] = -3.0e38f;
+      cm = fmaxf(cm, f[j]);
+    }
+    const float nm = fmaxf(mx, cm);
+    float cs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs += (c * 8 + j < V) ? __expf(f[j] - nm) : 0.f;
+    sm = sm * __expf(mx - nm) + cs;
+    mx = nm;
+  }
+  const float wm = wave_max(mx);
+  sm = wave_sum(sm * __expf(mx - wm));
+  if (lane == 0) { red_m[wave] = wm; red_s[wave] = sm; }
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  float bs = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bs += red_s[w] * __expf(red_m[w] - bm);
+  const float lse = bm + logf(bs);
+  if (tid == 0) row_loss[m] = lse - bf16_to_f32(logits[(size_t)m * Vp + tgt]);
+  if (dl) {
+    const float sc = 1.f / denom[0];
+    for (int c = tid; c < nch; c += 256) {
+      float f[8], o[8];
+      unpack_bf16x8(lr[c], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = c * 8 + j;
+        float pj = col < V ? __expf(f[j] - lse) : 0.f;
+        if (col == (int)tgt) pj -= 1.f;
+        o[j] = pj * sc;
+      }
+      dl[c] = pack_bf16x8(o);
+    }
+  }
+}
+
+// ---- gather-side embedding gradient for large vocabularies -------------------------------------
+// dE[v] += sum over tokens m with ids[m] == v of dh[m], summed in token order (deterministic, no float
+// atomics): rank[m] = number of earlier tokens with the same id (brute force through LDS, M^2/2
+// integer compares), count[v] by integer atomics, exclusive scan -> list of token indices per id.
+__global__ __launch_bounds__(256) void embed_rank_kernel(const int64_t* __restrict__ ids, int M, int V, int pad_id,
+                                                         int* __restrict__ rank, int* __restrict__ count) {
+  __shared__ int sid[256];
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  int64_t id64 = m < M ? ids[m] : -1;
+  const int id = (id64 >= 0 && id64 < V && id64 != pad_id) ? (int)id64 : -1;
+  int r = 0;
+  for (int base = 0; base <= blockIdx.x * 256; base += 256) {
+    const int j = base + threadIdx.x;
+    int64_t v = j < M ? ids[j] : -1;
+    __syncthreads();
+    sid[threadIdx.x] = (v >= 0 && v < V) ? (int)v : -2;
+    __syncthreads();
+    const int lim = min(256, m - base);  // only tokens before m
+    for (int k = 0; k < lim; ++k) r += (sid[k] == id);
+  }
+  if (m < M) {
+    rank[m] = r;
+    if (id >= 0) atomicAdd(count + id, 1);
+  }
+}
+// offset = exclusive scan of count (single block of 1024 threads, each a contiguous slice)
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ count, int* __restrict__ offset, int V) {
+  __shared__ int part[1024];
+  const int per = (V + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(V, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += count[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int i = lo; i < hi; ++i) { offset[i] = run; run += count[i]; }
+}
+__global__ __launch_bounds__(256) void embed_fill_kernel(const int64_t* __restrict__ ids, int M, int V, int pad_id,
+                                                         const int* __restrict__ rank, const int* __restrict__ offset,
+                                                         int* __restrict__ list) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int64_t id = ids[m];
+  if (id >= 0 && id < V && id != pad_id) list[offset[id] + rank[m]] = m;
+}
+// one block per vocabulary row with at least one token; thread = 8 columns
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const bf16_t* __restrict__ dh, float* __restrict__ dE, int H,
+                                                            const int* __restrict__ count, const int* __restrict__ offset,
+                                                            const int* __restrict__ list) {
+  const int v = blockIdx.x;
+  const int n = count[v];
+  if (n == 0) return;
+  const int* l = list + offset[v];
+  for (int c = threadIdx.x; c < (H >> 3); c += 256) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dh + (size_t)l[j] * H + c * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f[k];
+    }
+    float4* o = reinterpret_cast<float4*>(dE + (size_t)v * H + c * 8);
+    float4 a = o[0], b = o[1];
+    o[0] = make_float4(a.x + acc[0], a.y + acc[1], a.z + acc[2], a.w + acc[3]);
+    o[1] = make_float4(b.x + acc[4], b.y + acc[5], b.z + acc[6], b.w + acc[7]);
   }
 }
 
@@ -606,8 +747,11 @@ int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, floa
   LAUNCH_RET();
 }
 
-int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, const float* sn, int backward, hipStream_t st) {
-  rope_kernel<<<nblocks((size_t)M * nrot_heads * 4, 256), 256, 0, st>>>(qkv, ld, M, nrot_heads, cs, sn, backward ? -1.f : 1.f);
+int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, int head_dim, const float* cs, const float* sn, int backward,
+               hipStream_t st) {
+  if (head_dim & 15) return -1;
+  rope_kernel<<<nblocks((size_t)M * nrot_heads * (head_dim / 16), 256), 256, 0, st>>>(qkv, ld, M, nrot_heads, head_dim, cs, sn,
+                                                                                     backward ? -1.f : 1.f);
   LAUNCH_RET();
 }
 
@@ -631,12 +775,30 @@ int onehot(const int64_t* ids, bf16_t* oh, int M, int Vp, int V, int pad_id, hip
   LAUNCH_RET();
 }
 
+size_t embed_bwd_workspace_ints(int M, int Vp) { return (size_t)2 * M + 2 * (size_t)Vp + 64; }
+int embed_bwd(const int64_t* ids, const bf16_t* dh, float* dE, int M, int H, int Vp, int V, int pad_id, int* ws,
+              hipStream_t st) {
+  if (H & 7) return -1;
+  int* rank = ws;
+  int* list = ws + M;
+  int* count = ws + 2 * (size_t)M;
+  int* offset = count + Vp;
+  hipError_t e = hipMemsetAsync(count, 0, (size_t)Vp * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  embed_rank_kernel<<<(M + 255) / 256, 256, 0, st>>>(ids, M, V, pad_id, rank, count);
+  embed_scan_kernel<<<1, 1024, 0, st>>>(count, offset, V);
+  embed_fill_kernel<<<(M + 255) / 256, 256, 0, st>>>(ids, M, V, pad_id, rank, offset, list);
+  embed_scatter_kernel<<<V, 256, 0, st>>>(dh, dE, H, count, offset, list);
+  LAUNCH_RET();
+}
+
 int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
                   float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st) {
-  if (Vp != 512) return -1;
+  if (Vp < 512 || (Vp & 7) || V > Vp) return -1;
   int M = B * T;
   count_valid_kernel<<<1, 256, 0, st>>>(labels, B, T, num_items, denom);
-  ce_kernel<<<(M + 3) / 4, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
+  if (Vp == 512) ce_kernel<<<(M + 3) / 4, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
+  else ce_big_kernel<<<M, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
   loss_finish_kernel<<<1, 256, 0, st>>>(row_loss, M, denom, loss);
   LAUNCH_RET();
 }

@@ -17,7 +17,7 @@ using namespace slam;
 
 namespace {
 
-constexpr int VPAD = 512;
+constexpr int VPAD_SMALL = 512;  // vocabularies up to 512 (the speech-unit LMs) use the one-wave CE and one-hot wgrad paths
 constexpr int GU_BLK = 32;  // Wgu rows / gate|up columns come in blocks of 32 gate + 32 up
 
 struct LayerOff {
@@ -42,6 +42,7 @@ __global__ void seg_fill_kernel(int* seg_start, int* seg_end, int M, int T) {
 struct SlamEngine {
   SlamModelDesc d;
   int QKV;  // (nH + 2 nKV) * hd
+  int vpad = VPAD_SMALL;  // embedding / logits rows: 512, or vocab rounded up to 128 beyond that
   int64_t n_params;
   int64_t off_embed, off_norm, layer_stride = 0;
   std::vector<LayerOff> lo;
@@ -59,6 +60,7 @@ struct SlamEngine {
   std::vector<bf16_t*> hs;  // L+1 residual streams
   std::vector<LayerAct> la;
   bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
+  int* embed_ws = nullptr;
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -100,7 +102,7 @@ size_t max_gemm_ws(const SlamEngine* e, int M) {
   upd(d.hidden, d.n_heads * d.head_dim);
   upd(2 * d.intermediate, d.hidden);
   upd(d.hidden, d.intermediate);
-  upd(VPAD, d.hidden);
+  upd(e->vpad, d.hidden);
   return w;
 }
 
@@ -126,9 +128,11 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   }
   e->hf = c.take<bf16_t>(M * H);
   e->rstdf = c.take<float>(M);
-  e->logits = c.take<bf16_t>(M * VPAD);
-  e->dlogits = c.take<bf16_t>(M * VPAD);
-  e->onehot = c.take<bf16_t>(M * VPAD);
+  const size_t VP = (size_t)e->vpad;
+  e->logits = c.take<bf16_t>(M * VP);
+  e->dlogits = c.take<bf16_t>(M * VP);
+  if (e->vpad == VPAD_SMALL) { e->onehot = c.take<bf16_t>(M * VP); e->embed_ws = nullptr; }
+  else { e->onehot = nullptr; e->embed_ws = c.take<int>(embed_bwd_workspace_ints((int)M, e->vpad)); }
   e->row_loss = c.take<float>(M);
   e->dh_a = c.take<bf16_t>(M * H);
   e->dh_b = c.take<bf16_t>(M * H);
@@ -137,7 +141,7 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->dqkv = c.take<bf16_t>(M * e->QKV);
   e->d_o = c.take<bf16_t>(M * d.n_heads * d.head_dim);
   e->dsum = c.take<float>(M * d.n_heads);
-  e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_heads) / sizeof(float));
+  e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_heads, d.head_dim) / sizeof(float));
   e->cosb = c.take<float>(M * (d.head_dim / 2));
   e->sinb = c.take<float>(M * (d.head_dim / 2));
   e->seg_s = c.take<int>(M);
@@ -188,16 +192,17 @@ const char* slam_version(void) { return "slam-engine gfx950 r1"; }
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
   const SlamModelDesc& d = *desc;
-  if (d.head_dim != 64 || d.n_heads <= 0 || d.n_kv_heads <= 0 || d.n_heads % d.n_kv_heads) return SLAM_EINVAL;
-  if (d.hidden % 8 || d.hidden > 2048 || d.intermediate % GU_BLK || d.vocab <= 0 || d.vocab > VPAD) return SLAM_EINVAL;
+  if ((d.head_dim != 64 && d.head_dim != 128) || d.n_heads <= 0 || d.n_kv_heads <= 0 || d.n_heads % d.n_kv_heads) return SLAM_EINVAL;
+  if (d.hidden % 8 || d.hidden > 2048 || d.intermediate % GU_BLK || d.vocab <= 0) return SLAM_EINVAL;
   if (d.n_layers <= 0) return SLAM_EINVAL;
   SlamEngine* e = new SlamEngine();
   e->d = d;
   e->QKV = (d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
+  e->vpad = d.vocab <= VPAD_SMALL ? VPAD_SMALL : ((d.vocab + 127) / 128) * 128;
   e->fuse_swiglu = (d.hidden % 64 == 0) && ((2 * d.intermediate) % 128 == 0);
   int64_t off = 0;
   e->off_embed = off;
-  add_tensor(e, "embed", off, VPAD, d.hidden);
+  add_tensor(e, "embed", off, e->vpad, d.hidden);
   e->lo.resize(d.n_layers);
   for (int l = 0; l < d.n_layers; ++l) {
     std::string p = "layers." + std::to_string(l) + ".";
@@ -242,7 +247,7 @@ int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream) {
   const bf16_t* P = h->params;
   bf16_t* Pt = h->params_t;
   const int H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
-  CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, VPAD, H, 1, 0, st));
+  CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, h->vpad, H, 1, 0, st));
   // every layer has the same shapes at a constant stride: one launch per weight kind, grid.z = layers
   const LayerOff& o = h->lo[0];
   const int L = d.n_layers;
@@ -266,6 +271,7 @@ size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens) {
   SlamEngine tmp;
   tmp.d = h->d;
   tmp.QKV = h->QKV;
+  tmp.vpad = h->vpad;
   return carve(&tmp, nullptr, max_tokens);
 }
 int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_tokens) {
@@ -322,11 +328,11 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
-    if ((H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
+    if (d.head_dim == 64 && (H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
       CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, nH + nKV, M, h->QKV, H, st));
     } else {
       CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
-      CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, h->cosb, h->sinb, 0, st));
+      CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, d.head_dim, h->cosb, h->sinb, 0, st));
     }
     CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
@@ -340,15 +346,16 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
   CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
-  CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VPAD, H, st));
+  const int VP = h->vpad;
+  CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
   h->have_loss = false;
   if (labels) {
-    CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VPAD,
+    CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VP,
                      d.vocab, st));
     CK((int)hipMemcpyAsync(loss_out, h->scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     h->have_loss = true;
   }
-  if (logits_out) CK(copy_cols(h->logits, VPAD, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
+  if (logits_out) CK(copy_cols(h->logits, VP, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
   h->B = B;
   h->T = T;
   h->last_ids = ids;
@@ -374,10 +381,11 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   auto dgrad = [&](const bf16_t* dY, int64_t woff, bf16_t* dX, int N, int K) -> int {
     return Pt ? gemm_nt(dY, Pt + woff, dX, nullptr, nullptr, M, K, N, st) : gemm_nn(dY, P + woff, dX, nullptr, M, N, K, st);
   };
-  if (grad_scale != 1.0f) CK(scale_bf16(h->dlogits, (size_t)M * VPAD, grad_scale, st));
+  const int VP = h->vpad;
+  if (grad_scale != 1.0f) CK(scale_bf16(h->dlogits, (size_t)M * VP, grad_scale, st));
   // tied head: dE += dlogits^T hf ; dhf = dlogits E
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, 1, M, VPAD, H, VPAD, H, h->gemm_ws, st));
-  CK(dgrad(h->dlogits, h->off_embed, h->dx, VPAD, H));
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, st));
+  CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
   CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, 1, h->part_ws, M, H, st));
@@ -422,9 +430,14 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       bucket_end = o.ln1;
     }
   }
-  // gather-side embedding gradient: dE += onehot(ids)^T dh0 (padding_idx column suppressed)
-  CK(onehot(h->last_ids, h->onehot, M, VPAD, d.vocab, d.pad_token_id, st));
-  CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VPAD, H, VPAD, H, h->gemm_ws, st));
+  // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
+  // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
+  if (VP == VPAD_SMALL) {
+    CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, st));
+    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, st));
+  } else {
+    CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, st));
+  }
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;
@@ -441,7 +454,7 @@ int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, 
 int slam_scale_loss_rows(SlamEngine* h, const float* seq_coef, int32_t B, int32_t T, slam_stream_t stream) {
   if (!h || !seq_coef) return SLAM_EINVAL;
   if (!h->have_loss || B != h->B || T != h->T) return h->fail(SLAM_ESTATE, "scale_loss_rows needs the matching forward with labels");
-  CK(scale_rows_bf16(h->dlogits, seq_coef, B * T, T, VPAD, (hipStream_t)stream));
+  CK(scale_rows_bf16(h->dlogits, seq_coef, B * T, T, h->vpad, (hipStream_t)stream));
   return SLAM_OK;
 }
 
@@ -502,11 +515,12 @@ int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const floa
   return rmsnorm_bwd((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw,
                      0, ws, M, H, (hipStream_t)s);
 }
-int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, const int64_t* position_ids, float theta,
+int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, int head_dim, const int64_t* position_ids, float theta,
                  int backward, float* cs_ws, slam_stream_t s) {
-  int r = rope_table(position_ids, M, T, 64, theta, cs_ws, cs_ws + (size_t)M * 32, (hipStream_t)s);
+  const size_t half = (size_t)head_dim / 2;
+  int r = rope_table(position_ids, M, T, head_dim, theta, cs_ws, cs_ws + (size_t)M * half, (hipStream_t)s);
   if (r) return r;
-  return rope_apply((bf16_t*)qkv, ld, M, n_rot_heads, cs_ws, cs_ws + (size_t)M * 32, backward, (hipStream_t)s);
+  return rope_apply((bf16_t*)qkv, ld, M, n_rot_heads, head_dim, cs_ws, cs_ws + (size_t)M * half, backward, (hipStream_t)s);
 }
 int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s) {
   return swiglu_fwd((const bf16_t*)gu, (bf16_t*)act, M, I, I, (hipStream_t)s);
@@ -515,26 +529,32 @@ int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s
   return swiglu_bwd((bf16_t*)gu, (const bf16_t*)dact, M, I, I, (hipStream_t)s);
 }
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
-                     slam_stream_t s) {
-  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, M, nH, nKV, 64, (hipStream_t)s);
+                     int head_dim, slam_stream_t s) {
+  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
 }
-size_t slam_op_attn_bwd_workspace(int M, int nH) {
-  return attn_bwd_workspace_bytes(M, nH) + (size_t)M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
+size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim) {
+  return attn_bwd_workspace_bytes(M, nH, head_dim) + (size_t)M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
 }
 int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
-                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, slam_stream_t s) {
+                     const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, int head_dim,
+                     slam_stream_t s) {
   float* dsum = ws;
   float* part = ws + (size_t)M * nH;
-  int* plan = reinterpret_cast<int*>(part + attn_bwd_workspace_bytes(M, nH) / sizeof(float));
+  int* plan = reinterpret_cast<int*>(part + attn_bwd_workspace_bytes(M, nH, head_dim) / sizeof(float));
   int r = attn_plan(seg_start, seg_end, M, plan, (hipStream_t)s);
   if (r) return r;
   return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, dsum, (bf16_t*)dqkv, part, seg_start,
-                  seg_end, plan, nullptr, nullptr, M, nH, nKV, 64, (hipStream_t)s);
+                  seg_end, plan, nullptr, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
 }
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
-                          float* scratch2, int B, int T, int V, slam_stream_t s) {
+                          float* scratch2, int B, int T, int Vp, int V, slam_stream_t s) {
   return cross_entropy((const bf16_t*)logits, labels, num_items, (bf16_t*)dlogits, row_loss, scratch2, scratch2 + 1, B,
-                       T, VPAD, V, (hipStream_t)s);
+                       T, Vp, V, (hipStream_t)s);
+}
+size_t slam_op_embed_bwd_workspace(int M, int Vp) { return embed_bwd_workspace_ints(M, Vp) * sizeof(int); }
+int slam_op_embed_bwd(const int64_t* ids, const void* dh, float* dE, int M, int H, int Vp, int V, int pad_id, void* ws,
+                      slam_stream_t s) {
+  return embed_bwd(ids, (const bf16_t*)dh, dE, M, H, Vp, V, pad_id, (int*)ws, (hipStream_t)s);
 }
 
 }  // extern "C"

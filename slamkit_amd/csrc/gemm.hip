@@ -477,17 +477,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   }
 }
 
-// ---- experimental: same 128x128x64 DMA ring, 32x32x16 MFMA (2x2 fragments of 32x32 per wave) ------
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-SLAM_DEVICE f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__global__ __launch_bounds__(256, 2) void gemm_nt32_kernel(GemmArgs p) {
+// ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
+//      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
+//      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
+//      swizzle key4(row) = (-(row>>2)) & 3 (conflict-free for the 16-row ds_read_b128 fragments).
+SLAM_DEVICE int key4(int row) { return (0 - (row >> 2)) & 3; }
+template <int NSTAGE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_k32_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NSTAGE = 2;
+  constexpr int BK2 = 32, TILE2 = 128 * 64, STAGE2 = 2 * TILE2, D = NSTAGE - 1, PT = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, hb = lane >> 5;
+  const int l15 = lane & 15, g = lane >> 4;
   const int nblk = p.tiles_r * p.tiles_c;
   int nid;
   {
@@ -495,82 +496,114 @@ __global__ __launch_bounds__(256, 2) void gemm_nt32_kernel(GemmArgs p) {
     int q = nblk >> 3, r = nblk & 7;
     nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int row0 = (nid / p.tiles_c) * BM, col0 = (nid % p.tiles_c) * BN;
-  const int nk = (p.Kc + BK - 1) / BK;
-  f32x16_t acc[2][2];
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * BM, col0 = tc_ * BN;
+  const int nk = p.Kc / BK2;
+  f32x4_t acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // row = w*64 + f*32 + l31: key8 = ((l31>>1) ^ (w*4 + f*2 + (l31>>4))) & 7
-  const int s0a = ((l31 >> 1) ^ (wn * 4) ^ (l31 >> 4)) & 7, s0b = ((l31 >> 1) ^ (wm * 4) ^ (l31 >> 4)) & 7;
-  const int a_base = (wn * 64 + l31) * 128, b_base = (wm * 64 + l31) * 128;
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // row = w*64 + f*16 + l15 -> key4 depends on l15 only
+  const int chunk = (g ^ key4(l15)) << 4;
+  const int a_off = (wn * 64 + l15) * 64 + chunk;
+  const int b_off = (wm * 64 + l15) * 64 + chunk;
   auto compute = [&](int s) {
-    const char* At = smem + s * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
+    const char* At = smem + s * STAGE2;
+    const char* Bt = At + TILE2;
+    uint4 af[4], bf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ch = hb + 2 * ks;
-      uint4 af[2], bf[2];
+    for (int f = 0; f < 4; ++f) af[f] = *reinterpret_cast<const uint4*>(Bt + a_off + f * 16 * 64);
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 32 * 128 + ((ch ^ s0a ^ (f * 2)) << 4));
-        bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 32 * 128 + ((ch ^ s0b ^ (f * 2)) << 4));
-      }
+    for (int f = 0; f < 4; ++f) bf[f] = *reinterpret_cast<const uint4*>(At + b_off + f * 16 * 64);
 #pragma unroll
-      for (int fm = 0; fm < 2; ++fm)
+    for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn) acc[fm][fn] = mfma32(af[fn], bf[fm], acc[fm][fn]);
-    }
+      for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
   };
   const uint32_t lds0 = lds_addr(smem);
-  uint32_t voa[4], vob[4];
-  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
-  glds_offsets<256, 128>(p.ldb, p.Cn, col0, tid, vob);
+  uint32_t voa[2], vob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int P = i * 256 + tid, row = P >> 2, c = (P & 3) ^ key4(row);
+    int ra = row0 + row, rb = col0 + row;
+    ra = ra < p.R ? ra : p.R - 1;
+    rb = rb < p.Cn ? rb : p.Cn - 1;
+    voa[i] = (uint32_t)(((size_t)ra * p.lda + c * 8) * sizeof(bf16_t));
+    vob[i] = (uint32_t)(((size_t)rb * p.ldb + c * 8) * sizeof(bf16_t));
+  }
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE_BYTES);
-    glds_tile<256, 128>(p.A + t * BK, voa, wv, st);
-    glds_tile<256, 128>(p.B + t * BK, vob, wv, st + TILE_BYTES);
+    const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE2);
+    const bf16_t* ga = p.A + t * BK2;
+    const bf16_t* gb = p.B + t * BK2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16_sv(ga, voa[i], __builtin_amdgcn_readfirstlane(st + (uint32_t)(i * 256 + wv * 64) * 16u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16_sv(gb, vob[i], __builtin_amdgcn_readfirstlane(st + TILE2 + (uint32_t)(i * 256 + wv * 64) * 16u));
   };
-  if (nk > 0) issue(0);
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s);
   for (int t = 0; t < nk; ++t) {
-    wait_vmcnt<0>();
+    const int rem = min(D - 1, nk - 1 - t);
+    switch (rem) {
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<PT>(); break;
+      case 2: wait_vmcnt<2 * PT>(); break;
+      case 3: wait_vmcnt<3 * PT>(); break;
+      default: wait_vmcnt<4 * PT>(); break;
+    }
     __syncthreads();
-    if (t + 1 < nk) issue(t + 1);
+    if (t + D < nk) issue(t + D);
     compute(t % NSTAGE);
   }
-  // D[i = n][j = m]: lane holds m = l31 (+32 fm), n = 8*(r>>2) + 4*hb + (r&3) (+32 fn)
+  uint2 bb[4];
+  if (p.bias) {
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm) {
-    const int m = row0 + wm * 64 + fm * 32 + l31;
+    for (int fn = 0; fn < 4; ++fn) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + wn * 64 + fn * 16 + g * 4);
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + wm * 64 + fm * 16 + l15;
     const bool mok = m < p.R;
     const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+    uint2 rr[4];
+    if (p.resid) {
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
+      for (int fn = 0; fn < 4; ++fn) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wn * 64 + fn * 16 + g * 4);
+    }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = col0 + wn * 64 + fn * 32 + 8 * q + 4 * hb;
-        float v0 = acc[fm][fn][4 * q], v1 = acc[fm][fn][4 * q + 1], v2 = acc[fm][fn][4 * q + 2], v3 = acc[fm][fn][4 * q + 3];
-        if (p.bias) {
-          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + n);
-          v0 += __uint_as_float(bb.x << 16); v1 += __uint_as_float(bb.x & 0xffff0000u);
-          v2 += __uint_as_float(bb.y << 16); v3 += __uint_as_float(bb.y & 0xffff0000u);
-        }
-        if (p.resid) {
-          uint2 rr = *reinterpret_cast<const uint2*>(p.resid + rowoff + n);
-          v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
-          v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack_bf16x2(v0, v1);
-        o.y = pack_bf16x2(v2, v3);
-        if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
+    for (int fn = 0; fn < 4; ++fn) {
+      const int n = col0 + wn * 64 + fn * 16 + g * 4;
+      f32x4_t v = acc[fm][fn];
+      if (p.bias) {
+        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
       }
+      if (p.resid) {
+        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
+    }
   }
 }
+template <int NSTAGE>
+int launch_k32(GemmArgs a, hipStream_t st);
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
@@ -604,6 +637,21 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+template <int NSTAGE>
+int launch_k32(GemmArgs a, hipStream_t st) {
+  constexpr int lds = NSTAGE * 2 * 128 * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k32_kernel<NSTAGE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  a.group_rows = g_group_rows;
+  gemm_nt_k32_kernel<NSTAGE><<<a.tiles_r * a.tiles_c, 256, lds, st>>>(a);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 namespace slam {
@@ -633,17 +681,9 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
     case 2: return launch<false, false, false, 2>(a, 1, st);
     case 3: return launch<false, false, false, 3>(a, 1, st);
     case 4: return launch<false, false, false, 4>(a, 1, st);
-    case 32: {
-      static bool attr = false;
-      if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-      }
-      gemm_nt32_kernel<<<a.tiles_r * a.tiles_c, 256, 2 * STAGE_BYTES, st>>>(a);
-      return (int)hipGetLastError();
-    }
+    case 323: return launch_k32<3>(a, st);
+    case 324: return launch_k32<4>(a, st);
+    case 325: return launch_k32<5>(a, st);
     case 82: return launch<false, false, false, 2, 8>(a, 1, st);
     case 162: return launch<false, false, false, 2, 8, 256>(a, 1, st);
     case 163: return launch<false, false, false, 3, 8, 256>(a, 1, st);

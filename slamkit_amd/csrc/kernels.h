@@ -32,8 +32,8 @@ size_t attn_plan_ints(int M);
 int attn_plan(const int* seg_start, const int* seg_end, int M, int* plan, hipStream_t st);
 int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH, int nKV,
              int head_dim, hipStream_t st);
-size_t attn_bwd_workspace_bytes(int M, int nH);
-// rope_cs / rope_sn (nullable): fp32 [M][32] tables; when given, dq and dk are written already
+size_t attn_bwd_workspace_bytes(int M, int nH, int head_dim);
+// rope_cs / rope_sn (nullable): fp32 [M][head_dim/2] tables; when given, dq and dk are written already
 // rotated back (transpose rotation), i.e. as gradients of the pre-RoPE projections
 int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* dsum, bf16_t* dqkv,
              float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, const float* rope_cs,
@@ -47,12 +47,17 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
 int colsum_blocks(int M);
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st);
 int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st);
-int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, const float* cs, const float* sn, int backward,
+int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, int head_dim, const float* cs, const float* sn, int backward,
                hipStream_t st);
 int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, int blk, hipStream_t st);
 int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, int blk, hipStream_t st);
 int embed_fwd(const int64_t* ids, const bf16_t* E, bf16_t* out, int M, int H, int V, hipStream_t st);
 int onehot(const int64_t* ids, bf16_t* oh, int M, int Vp, int V, int pad_id, hipStream_t st);
+// gather-side embedding gradient for large vocabularies: dE[ids[m]] += dh[m] in token order (deterministic);
+// ws = embed_bwd_workspace_ints(M, Vp) ints
+size_t embed_bwd_workspace_ints(int M, int Vp);
+int embed_bwd(const int64_t* ids, const bf16_t* dh, float* dE, int M, int H, int Vp, int V, int pad_id, int* ws,
+              hipStream_t st);
 int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
                   float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st);
 int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float* ll, float* cnt, hipStream_t st);

@@ -79,13 +79,15 @@ def load_library(path: Optional[str] = None):
         "slam_op_rmsnorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
         "slam_op_rmsnorm_bwd_workspace": (sz, [C.c_int, C.c_int]),
         "slam_op_rmsnorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
-        "slam_op_rope": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, C.c_int, vp, vp]),
+        "slam_op_rope": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, C.c_int, vp, vp]),
         "slam_op_swiglu_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "slam_op_swiglu_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
-        "slam_op_attn_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-        "slam_op_attn_bwd_workspace": (sz, [C.c_int, C.c_int]),
-        "slam_op_attn_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-        "slam_op_cross_entropy": (C.c_int, [vp, vp, f64, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_attn_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_attn_bwd_workspace": (sz, [C.c_int, C.c_int, C.c_int]),
+        "slam_op_attn_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_cross_entropy": (C.c_int, [vp, vp, f64, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_embed_bwd_workspace": (sz, [C.c_int, C.c_int]),
+        "slam_op_embed_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

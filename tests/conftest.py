@@ -23,3 +23,18 @@ def golden_npz():
 def golden_data():
     import json
     return json.load(open(os.path.join(GOLDEN, "data.json")))
+
+
+def load_wide_golden():
+    """tests/golden/wide_model.npz (make_golden_wide.py): head_dim 128, vocab 700, rope_theta 1e6."""
+    import numpy as np
+    g = dict(np.load(os.path.join(GOLDEN, "wide_model.npz")))
+    conv = {"rms_eps": float, "rope_theta": float}
+    cfg = {k: conv.get(k, int)(float(v)) for k, v in g["meta_config"]}
+    seed, bias_std, jit = g["meta_init"]
+    return g, cfg, int(seed), float(bias_std), float(jit)
+
+
+@pytest.fixture(scope="session")
+def wide_golden():
+    return load_wide_golden()

@@ -215,3 +215,112 @@ def test_slam358m_loss_and_grads_vs_oracle(B, T):
     # the loss of the whole batch is the token-weighted mean of per-row losses (checksum of checksums)
     rows = [float(m(input_ids=ids8[i:i + 1], labels=ids8[i:i + 1], return_logits=False).loss) for i in range(8)]
     assert abs(sum(rows) / 8 - l8) <= 2e-3
+
+
+# ---- config-4-shaped dims: head_dim 128, vocabulary beyond 512, rope_theta 1e6 ----------
+def test_wide_config_vs_reference_golden_and_oracle(wide_golden):
+    g, cfgd, seed, bias_std, jit = wide_golden
+    cfg = O.OracleConfig(**cfgd)
+    sd = O.init_weights(cfg, seed=seed, bias_std=bias_std, norm_jitter=jit)
+    sd_bf = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    m = _mk(cfg, sd)
+    ids, am, lab = (torch.from_numpy(g[k]) for k in ("pad_ids", "pad_mask", "pad_labels"))
+    out = m(input_ids=ids, attention_mask=am, labels=lab)
+    valid = am.bool()
+    check("wide logits vs reference golden", out.logits.float().cpu()[valid], torch.from_numpy(g["pad_logits"])[valid], 2e-2)
+    assert abs(float(out.loss) - float(g["pad_loss_mean"])) <= 2e-2
+    loss_ref, logits_ref, grads_ref = O.forward_loss_grads(cfg, sd_bf, ids, lab, attention_mask=am)
+    m.zero_grad()
+    out = m(input_ids=ids, attention_mask=am, labels=lab)
+    m.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out.loss) - float(loss_ref)) <= 5e-3
+    check("wide logits vs oracle", out.logits.float().cpu()[valid], logits_ref[valid], 1e-2)
+    grads = dict(m.named_grads())
+    for k, gv in grads.items():
+        small = k.endswith(".bias") or k.endswith("norm.weight")
+        c = cosine(gv, grads_ref[k])
+        assert c >= (0.99 if small else 0.999), f"{k}: cosine {c:.5f}"
+        assert abs(float(gv.norm()) / float(grads_ref[k].norm()) - 1) <= 3e-2, k
+    rows = torch.from_numpy(g["pad_embed_grad_rows"])
+    assert cosine(grads["lm.model.embed_tokens.weight"].cpu()[rows], torch.from_numpy(g["pad_embed_grad"])) >= 0.99
+    # packed batch (varlen attention, per-segment RoPE restart) and forward-only likelihood
+    ids, pos, lab = (torch.from_numpy(g[k]) for k in ("pack_ids", "pack_pos", "pack_labels"))
+    outp = m(input_ids=ids, position_ids=pos, labels=lab)
+    check("wide packed logits vs reference", outp.logits.float().cpu(), torch.from_numpy(g["pack_logits"]), 2e-2)
+    assert abs(float(outp.loss) - float(g["pack_loss_mean"])) <= 2e-2
+    _, _, gp_ref = O.forward_loss_grads(cfg, sd_bf, ids, lab, position_ids=pos, packed=True)
+    m.zero_grad()
+    m(input_ids=ids, position_ids=pos, labels=lab, return_logits=False)
+    m.backward()
+    for k, gv in m.named_grads():
+        small = k.endswith(".bias") or k.endswith("norm.weight")
+        assert cosine(gv, gp_ref[k]) >= (0.99 if small else 0.999), k
+    ll = m.log_likelihood(torch.from_numpy(g["pad_ids"]), True).cpu().numpy()
+    assert np.allclose(ll, g["ll_mean"], rtol=5e-3, atol=2e-2)
+    # determinism of the large-vocabulary path (token-ordered embedding scatter, no float atomics)
+    g1 = m.flat_grads.clone()
+    m.zero_grad()
+    m(input_ids=ids, position_ids=pos, labels=lab, return_logits=False)
+    m.backward()
+    assert torch.equal(m.flat_grads, g1)
+
+
+def test_qwen15b_shaped_layers_vs_oracle():
+    """Two layers of the Qwen2.5-1.5B shape (H 1536, 12/2 heads of 128, I 8960) with a 20k vocabulary, T 256."""
+    cfg = O.OracleConfig(n_layers=2, hidden=1536, n_heads=12, n_kv_heads=2, head_dim=128, intermediate=8960, vocab=20003,
+                         rope_theta=1000000.0)
+    sd = O.init_weights(cfg, seed=1)
+    sd_bf = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    m = _mk(cfg, sd, max_tokens=2048)
+    gen = torch.Generator().manual_seed(99)
+    ids = torch.randint(2, cfg.vocab, (2, 256), generator=gen)
+    ids[:, 0] = 1
+    ids[1, 200:] = 0
+    lab = ids.clone()
+    lab[ids == 0] = -100
+    am = (ids != 0).long()
+    loss_ref, logits_ref, grads_ref = O.forward_loss_grads(cfg, sd_bf, ids, lab, attention_mask=am)
+    m.zero_grad()
+    out = m(input_ids=ids, attention_mask=am, labels=lab)
+    m.backward()
+    torch.cuda.synchronize()
+    print("qwen1.5b-shaped loss engine/oracle", float(out.loss), float(loss_ref))
+    assert abs(float(out.loss) - float(loss_ref)) <= 2e-2
+    check("qwen1.5b-shaped logits", out.logits.float().cpu()[am.bool()], logits_ref[am.bool()], 2e-2)
+    for k, gv in m.named_grads():
+        small = k.endswith(".bias") or k.endswith("norm.weight")
+        c = cosine(gv, grads_ref[k])
+        assert c >= (0.99 if small else 0.998), f"{k}: cosine {c:.5f}"
+
+
+def test_full_vocab_152k_properties():
+    """V = 152,167 (Qwen2.5 tokenizer + 500 units + 2 markers): size-independent properties only."""
+    cfg = O.OracleConfig(n_layers=1, hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=152167,
+                         rope_theta=1000000.0)
+    m = _mk(cfg, None, max_tokens=4096)
+    gen = torch.Generator().manual_seed(7)
+    ids = torch.randint(2, cfg.vocab, (2, 1024), generator=gen)
+    ids[:, 0] = 1
+    out = m(input_ids=ids, labels=ids, return_logits=False)
+    l0 = float(out.loss)
+    assert abs(l0 - math.log(cfg.vocab)) < 0.5, l0
+    m.zero_grad()
+    m.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.flat_grads).all())
+    g1 = m.flat_grads.clone()
+    eg = dict(m.named_grads())["lm.model.embed_tokens.weight"]
+    assert eg.shape == (cfg.vocab, cfg.hidden)
+    # rows of ids that occur get a gather-side contribution far above the tied-head one
+    seen = torch.zeros(cfg.vocab, dtype=torch.bool)
+    seen[ids.flatten()] = True
+    rn = eg.float().norm(dim=1).cpu()
+    assert float(rn[seen].mean()) > 3 * float(rn[~seen].mean())
+    perm = torch.tensor([1, 0])
+    m.zero_grad()
+    o2 = m(input_ids=ids[perm], labels=ids[perm], return_logits=False)
+    m.backward()
+    torch.cuda.synchronize()
+    assert abs(float(o2.loss) - l0) <= 1e-5
+    assert rel_err(m.flat_grads, g1) <= 2e-3

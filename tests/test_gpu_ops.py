@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("glds", [0, 1, 3, 4, 32, 83, 84, 162, 163])
+@pytest.mark.parametrize("glds", [0, 1, 3, 4, 323, 325, 83, 84, 162, 163])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 256, 128), (1000, 1152, 896),
                                    (74, 512, 256)])
 def test_gemm_nt(M, N, K, glds):
@@ -89,30 +89,31 @@ def test_rmsnorm_fwd_bwd(M, H):
 
 
 # ------------------------------------------------------------------------------------------ RoPE
+@pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("packed", [False, True])
-def test_rope(packed):
+def test_rope(packed, hd):
     B, T, nH, nKV = 2, 75, 4, 2
-    M, ld = B * T, (nH + 2 * nKV) * 64
+    M, ld = B * T, (nH + 2 * nKV) * hd
     qkv = rnd(M, ld, seed=1)
     if packed:
         pos = torch.cat([torch.arange(40), torch.arange(60), torch.arange(50)])[None]
     else:
         pos = torch.arange(T)[None].expand(B, T)
     buf = dev_bf16(qkv)
-    cs = torch.empty(2 * M * 32, dtype=torch.float32, device="cuda")
+    cs = torch.empty(2 * M * (hd // 2), dtype=torch.float32, device="cuda")
     posd = pos.reshape(-1).contiguous().cuda() if packed else None
-    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, ptr(posd), 10000.0, 0, ptr(cs), stream()) == 0
+    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, hd, ptr(posd), 10000.0, 0, ptr(cs), stream()) == 0
     sync()
-    q = qkv[:, : nH * 64].view(1, M, nH, 64).transpose(1, 2)
-    k = qkv[:, nH * 64: (nH + nKV) * 64].view(1, M, nKV, 64).transpose(1, 2)
-    cos, sin = O.rope_cos_sin(pos.reshape(1, M), 64, 10000.0)
+    q = qkv[:, : nH * hd].view(1, M, nH, hd).transpose(1, 2)
+    k = qkv[:, nH * hd: (nH + nKV) * hd].view(1, M, nKV, hd).transpose(1, 2)
+    cos, sin = O.rope_cos_sin(pos.reshape(1, M), hd, 10000.0)
     qr, kr = O.apply_rope(q, k, cos, sin)
     ref = qkv.clone()
-    ref[:, : nH * 64] = qr.transpose(1, 2).reshape(M, nH * 64)
-    ref[:, nH * 64: (nH + nKV) * 64] = kr.transpose(1, 2).reshape(M, nKV * 64)
+    ref[:, : nH * hd] = qr.transpose(1, 2).reshape(M, nH * hd)
+    ref[:, nH * hd: (nH + nKV) * hd] = kr.transpose(1, 2).reshape(M, nKV * hd)
     check("rope fwd", buf.float(), ref, 3e-3, 1e-2)
     # backward = transpose rotation: applying it to the forward result returns the input
-    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, ptr(posd), 10000.0, 1, ptr(cs), stream()) == 0
+    assert lib().slam_op_rope(ptr(buf), ld, M, T, nH + nKV, hd, ptr(posd), 10000.0, 1, ptr(cs), stream()) == 0
     sync()
     check("rope bwd(fwd(x)) == x", buf.float(), qkv, 6e-3, 3e-2)
 
@@ -137,13 +138,13 @@ def test_swiglu():
 
 
 # ------------------------------------------------------------------------------------- attention
-def _attn_case(seg_lens, nH, nKV, seed=0, spike=False):
+def _attn_case(seg_lens, nH, nKV, seed=0, spike=False, hd=64):
     M = sum(seg_lens)
-    ld = (nH + 2 * nKV) * 64
+    ld = (nH + 2 * nKV) * hd
     qkv = rnd(M, ld, seed=seed)
     if spike:  # force big running-max jumps in the online softmax
-        qkv[5, :64] *= 8.0   # powers of two keep the values bf16-representable
-        qkv[3, nH * 64: nH * 64 + 64] *= 8.0
+        qkv[5, :hd] *= 8.0   # powers of two keep the values bf16-representable
+        qkv[3, nH * hd: nH * hd + hd] *= 8.0
     starts = []
     s = 0
     for n in seg_lens:
@@ -159,77 +160,107 @@ def _attn_case(seg_lens, nH, nKV, seed=0, spike=False):
     return M, ld, qkv, seg_s, seg_e
 
 
-def _attn_ref(qkv, seg_s, nH, nKV, d_o=None):
+def _attn_ref(qkv, seg_s, nH, nKV, d_o=None, hd=64):
     M = qkv.shape[0]
     x = qkv.clone().requires_grad_(True)
-    q = x[:, : nH * 64].view(1, M, nH, 64).transpose(1, 2)
-    k = x[:, nH * 64: (nH + nKV) * 64].view(1, M, nKV, 64).transpose(1, 2)
-    v = x[:, (nH + nKV) * 64:].view(1, M, nKV, 64).transpose(1, 2)
+    q = x[:, : nH * hd].view(1, M, nH, hd).transpose(1, 2)
+    k = x[:, nH * hd: (nH + nKV) * hd].view(1, M, nKV, hd).transpose(1, 2)
+    v = x[:, (nH + nKV) * hd:].view(1, M, nKV, hd).transpose(1, 2)
     i = torch.arange(M)
     mask = ((i[None, :] <= i[:, None]) & (i[None, :] >= seg_s.long()[:, None]))[None]
-    o = O.attention(q, k, v, mask, 0.125).reshape(M, nH * 64)
+    o = O.attention(q, k, v, mask, hd ** -0.5).reshape(M, nH * hd)
     if d_o is None:
         return o.detach(), None
     o.backward(d_o)
     return o.detach(), x.grad
 
 
-@pytest.mark.parametrize("seg_lens,nH,nKV,spike", [
-    ([64], 2, 1, False), ([128], 2, 2, False), ([200], 4, 2, True), ([256, 256], 14, 2, False),
-    ([37, 100, 5, 130, 64], 4, 2, False), ([1024], 7, 1, False), ([29, 41, 17], 4, 2, True)])
-def test_attention_fwd_bwd(seg_lens, nH, nKV, spike):
-    M, ld, qkv, seg_s, seg_e = _attn_case(seg_lens, nH, nKV, seed=len(seg_lens), spike=spike)
-    d_o = rnd(M, nH * 64, seed=9)
-    o_ref, dqkv_ref = _attn_ref(qkv, seg_s, nH, nKV, d_o)
+@pytest.mark.parametrize("seg_lens,nH,nKV,spike,hd", [
+    ([64], 2, 1, False, 64), ([128], 2, 2, False, 64), ([200], 4, 2, True, 64), ([256, 256], 14, 2, False, 64),
+    ([37, 100, 5, 130, 64], 4, 2, False, 64), ([1024], 7, 1, False, 64), ([29, 41, 17], 4, 2, True, 64),
+    ([64], 2, 1, False, 128), ([200], 4, 2, True, 128), ([256, 256], 12, 2, False, 128),
+    ([37, 100, 5, 130, 64], 4, 2, False, 128), ([1024], 6, 1, False, 128), ([29, 41, 17], 4, 2, True, 128)])
+def test_attention_fwd_bwd(seg_lens, nH, nKV, spike, hd):
+    M, ld, qkv, seg_s, seg_e = _attn_case(seg_lens, nH, nKV, seed=len(seg_lens), spike=spike, hd=hd)
+    d_o = rnd(M, nH * hd, seed=9)
+    o_ref, dqkv_ref = _attn_ref(qkv, seg_s, nH, nKV, d_o, hd=hd)
     qd = dev_bf16(qkv)
-    o = torch.full((M, nH * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    o = torch.full((M, nH * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(nH * M, dtype=torch.float32, device="cuda")
     ss, se = seg_s.cuda(), seg_e.cuda()
-    assert lib().slam_op_attn_fwd(ptr(qd), ptr(o), ptr(lse), ptr(ss), M, nH, nKV, stream()) == 0
+    assert lib().slam_op_attn_fwd(ptr(qd), ptr(o), ptr(lse), ptr(ss), M, nH, nKV, hd, stream()) == 0
     sync()
-    check(f"attn fwd {seg_lens} nH={nH}", o.float(), o_ref, 6e-3, 3e-2)
+    check(f"attn fwd {seg_lens} nH={nH} hd={hd}", o.float(), o_ref, 6e-3, 3e-2)
     # lse check (log2 domain) against the scaled scores
-    q = qkv[:, : nH * 64].view(M, nH, 64).transpose(0, 1)
-    k = qkv[:, nH * 64: (nH + nKV) * 64].view(M, nKV, 64).transpose(0, 1).repeat_interleave(nH // nKV, 0)
-    s = (q @ k.transpose(1, 2)) * 0.125
+    q = qkv[:, : nH * hd].view(M, nH, hd).transpose(0, 1)
+    k = qkv[:, nH * hd: (nH + nKV) * hd].view(M, nKV, hd).transpose(0, 1).repeat_interleave(nH // nKV, 0)
+    s = (q @ k.transpose(1, 2)) * hd ** -0.5
     i = torch.arange(M)
     mask = (i[None, :] <= i[:, None]) & (i[None, :] >= seg_s.long()[:, None])
     s = s.masked_fill(~mask[None], float("-inf"))
     check("attn lse2", lse.view(nH, M).cpu(), torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4)
     # backward uses the bf16 O the forward produced (as the engine does)
-    ws = torch.empty(lib().slam_op_attn_bwd_workspace(M, nH) // 4 + 16, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib().slam_op_attn_bwd_workspace(M, nH, hd) // 4 + 16, dtype=torch.float32, device="cuda")
     dqkv = torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device="cuda")
     dod = dev_bf16(d_o)
     assert lib().slam_op_attn_bwd(ptr(qd), ptr(o), ptr(dod), ptr(lse), ptr(dqkv), ptr(ws), ptr(ss), ptr(se),
-                                  M, nH, nKV, stream()) == 0
+                                  M, nH, nKV, hd, stream()) == 0
     sync()
     got = dqkv.float().cpu()
-    check("attn bwd dq", got[:, : nH * 64], dqkv_ref[:, : nH * 64], 1.5e-2, 6e-2)
-    check("attn bwd dk", got[:, nH * 64: (nH + nKV) * 64], dqkv_ref[:, nH * 64: (nH + nKV) * 64], 1.5e-2, 6e-2)
-    check("attn bwd dv", got[:, (nH + nKV) * 64:], dqkv_ref[:, (nH + nKV) * 64:], 1.5e-2, 6e-2)
+    check("attn bwd dq", got[:, : nH * hd], dqkv_ref[:, : nH * hd], 1.5e-2, 6e-2)
+    check("attn bwd dk", got[:, nH * hd: (nH + nKV) * hd], dqkv_ref[:, nH * hd: (nH + nKV) * hd], 1.5e-2, 6e-2)
+    check("attn bwd dv", got[:, (nH + nKV) * hd:], dqkv_ref[:, (nH + nKV) * hd:], 1.5e-2, 6e-2)
 
 
 # --------------------------------------------------------------------------------- cross entropy
+@pytest.mark.parametrize("V,Vp", [(502, 512), (700, 768), (5003, 5120)])
 @pytest.mark.parametrize("num_items", [0.0, 57.0])
-def test_cross_entropy(num_items):
-    B, T, V = 3, 41, 502
+def test_cross_entropy(num_items, V, Vp):
+    B, T = 3, 41
     M = B * T
-    logits = rnd(M, 512, seed=1, scale=3.0)
+    logits = rnd(M, Vp, seed=1, scale=3.0)
     labels = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(2))
     labels[0, 5:9] = -100
     labels[2, 30:] = -100
     lg = dev_bf16(logits)
-    dl = torch.full((M, 512), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dl = torch.full((M, Vp), float("nan"), dtype=torch.bfloat16, device="cuda")
     rl = torch.empty(M, dtype=torch.float32, device="cuda")
     sc = torch.zeros(2, dtype=torch.float32, device="cuda")
     labd = labels.cuda()
-    assert lib().slam_op_cross_entropy(ptr(lg), ptr(labd), num_items, ptr(dl), ptr(rl), ptr(sc), B, T, V,
+    assert lib().slam_op_cross_entropy(ptr(lg), ptr(labd), num_items, ptr(dl), ptr(rl), ptr(sc), B, T, Vp, V,
                                        stream()) == 0
     sync()
     x = logits[:, :V].view(B, T, V).clone().requires_grad_(True)
     loss = O.compute_loss(x, labels, num_items_in_batch=(num_items if num_items > 0 else None))
     loss.backward()
     assert abs(float(sc[1]) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
-    got = dl.float().cpu().view(B, T, 512)
+    got = dl.float().cpu().view(B, T, Vp)
     check("ce dlogits", got[:, :, :V], x.grad, 5e-3, 2e-2)
     assert float(got[:, :, V:].abs().max()) == 0.0
+
+
+# ------------------------------------------------- gather-side embedding gradient, large vocabulary
+@pytest.mark.parametrize("M,V,Vp,H,hot", [(300, 700, 768, 64, False), (1000, 5003, 5120, 256, True), (777, 1000, 1024, 1536, True)])
+def test_embed_bwd_scatter(M, V, Vp, H, hot):
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (M,), generator=g)
+    if hot:  # a few very frequent ids and the suppressed padding id
+        ids[::3] = 7
+        ids[1::7] = 0
+        ids[5::11] = V - 1
+    dh = rnd(M, H, seed=3)
+    dE0 = torch.randn(Vp, H, generator=g)
+    ref = dE0.clone()
+    sel = ids != 0
+    ref.index_add_(0, ids[sel], dh[sel])
+    dhd, idd = dev_bf16(dh), ids.cuda()
+    dE = dE0.clone().cuda()
+    ws = torch.empty(lib().slam_op_embed_bwd_workspace(M, Vp) + 64, dtype=torch.uint8, device="cuda")
+    assert lib().slam_op_embed_bwd(ptr(idd), ptr(dhd), ptr(dE), M, H, Vp, V, 0, ptr(ws), stream()) == 0
+    sync()
+    check("embed bwd scatter", dE.cpu(), ref, 2e-5, 2e-4)
+    # bit-identical on a second run (token-ordered sums, no float atomics)
+    dE2 = dE0.clone().cuda()
+    assert lib().slam_op_embed_bwd(ptr(idd), ptr(dhd), ptr(dE2), M, H, Vp, V, 0, ptr(ws), stream()) == 0
+    sync()
+    assert torch.equal(dE, dE2)

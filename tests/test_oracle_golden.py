@@ -144,3 +144,32 @@ def test_clip_coef_matches_torch():
 def test_dpo_tokenize_row():
     r = O.dpo_tokenize_row([5, 6, 7, 8], [9, 10, 11], [12, 13], max_prompt_length=3, max_completion_length=3)
     assert r == {"prompt_input_ids": [6, 7, 8], "chosen_input_ids": [9, 10, 11], "rejected_input_ids": [12, 13, 1]}
+
+
+def test_wide_config_matches_reference(wide_golden):
+    """Config-4-shaped dims (head_dim 128, vocab 700 > 512, rope_theta 1e6): oracle vs the reference's vectors."""
+    g, cfgd, seed, bias_std, jit = wide_golden
+    cfg = O.OracleConfig(**cfgd)
+    assert (cfg.head_dim, cfg.vocab, cfg.rope_theta) == (128, 700, 1e6)
+    sd = O.init_weights(cfg, seed=seed, bias_std=bias_std, norm_jitter=jit)
+    ids, am, lab = (torch.from_numpy(g[k]) for k in ("pad_ids", "pad_mask", "pad_labels"))
+    loss, logits, grads = O.forward_loss_grads(cfg, sd, ids, lab, attention_mask=am)
+    valid = am.bool()
+    assert (logits[valid] - torch.from_numpy(g["pad_logits"])[valid]).abs().max() <= 2e-5
+    assert abs(float(loss) - float(g["pad_loss_mean"])) <= 1e-6
+    for k, gr in grads.items():
+        ref_norm = float(g["pad_gradnorm/" + k])
+        assert abs(float(gr.norm()) - ref_norm) <= 1e-5 * max(ref_norm, 1e-3), k
+    for key in [k for k in g if k.startswith("pad_gradfull/")]:
+        ref = torch.from_numpy(g[key])
+        assert (grads[key.split("/", 1)[1]] - ref).norm() <= 1e-5 * ref.norm() + 1e-9, key
+    rows = torch.from_numpy(g["pad_embed_grad_rows"])
+    ref = torch.from_numpy(g["pad_embed_grad"])
+    assert (grads["lm.model.embed_tokens.weight"][rows] - ref).norm() <= 1e-5 * ref.norm()
+    ids, pos, lab = (torch.from_numpy(g[k]) for k in ("pack_ids", "pack_pos", "pack_labels"))
+    with torch.no_grad():
+        logits = O.model_forward(cfg, sd, ids, position_ids=pos, packed=True)
+    assert (logits - torch.from_numpy(g["pack_logits"])).abs().max() <= 2e-5
+    assert abs(float(O.compute_loss(logits, lab)) - float(g["pack_loss_mean"])) <= 1e-6
+    ll = O.log_likelihood(cfg, sd, torch.from_numpy(g["pad_ids"]).clone(), True)
+    assert np.allclose(ll.numpy(), g["ll_mean"], rtol=1e-5, atol=1e-4)

@@ -1,0 +1,25 @@
+"""A/B of the experimental 128x128x32 deep-ring NT GEMM (modes 323/324/325) against mode 2."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slamkit_amd import engine as E
+lib = E.load_library()
+M = 8192; dev = "cuda"; st = E.current_stream_ptr()
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+def rb(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+modes = [int(a) for a in sys.argv[1:]] or [2, 323, 324, 325]
+for name, (N, K) in {"qkv fwd": (1152, 896), "o fwd": (896, 896), "gate_up fwd": (9728, 896), "down fwd": (896, 4864),
+                     "down dgrad": (4864, 896), "gate_up dgrad": (896, 9728)}.items():
+    x, w = rb(M, K), rb(N, K)
+    ref = None
+    for mode in modes:
+        y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, mode, st))
+        if ref is None: ref = y
+        ok = torch.equal(ref, y)
+        print(f"nt {name:16s} mode {mode:4d} {us:8.1f} us {2.0*M*N*K/us/1e6:8.1f} TF  same={ok}", flush=True)
