@@ -44,6 +44,39 @@ def synth_batch(rank: int, i: int, device):
     return {"input_ids": ids, "labels": ids}
 
 
+# --workload qwen1p5b (BASELINE.json configs[3], not the headline metric): Qwen2.5-1.5B-shaped body, mixed
+# unit + BPE vocabulary of 152,167 ids, ctx 2048, packed sequences (flattening collator layout)
+W4 = dict(name="Qwen/Qwen2.5-1.5B", vocab=152167, ctx=2048, tokens=16384, unit_lo=151667, n_mm=None)
+
+
+def synth_packed_batch(rank: int, i: int, device):
+    """[1, 16384] packed row: sequences of ~U{64..2048} tokens, 45 % of the ids from the unit range and 55 % from
+    the text range, position_ids restarting at each sequence, labels -100 at starts."""
+    g = torch.Generator().manual_seed(99 + rank + 1000 * i)
+    total, ids, pos, lab = W4["tokens"], [], [], []
+    while total > 0:
+        n = min(total, int(torch.randint(64, W4["ctx"] + 1, (1,), generator=g)))
+        unit = torch.rand(n, generator=g) < 0.45
+        t = torch.where(unit, torch.randint(W4["unit_lo"], W4["vocab"], (n,), generator=g),
+                        torch.randint(2, W4["unit_lo"], (n,), generator=g))
+        t[0] = 1
+        l = t.clone()
+        l[0] = -100
+        ids.append(t); pos.append(torch.arange(n)); lab.append(l)
+        total -= n
+    cat = lambda xs: torch.cat(xs)[None].to(device)  # noqa: E731
+    lens = [len(x) for x in ids]
+    return {"input_ids": cat(ids), "position_ids": cat(pos), "labels": cat(lab)}, lens
+
+
+def w4_flops_per_batch(lens):
+    """fwd+bwd algorithmic flops of one packed batch: 6 x matmul params per token + causal-exact attention."""
+    L, H, nH, hd, I, Vp = 28, 1536, 12, 128, 8960, W4["vocab"]
+    n_mm = L * (H * (nH + 4) * hd + nH * hd * H + 3 * H * I) + Vp * H
+    attn = sum(L * 4 * nH * hd * (n * (n + 1) / 2) for n in lens)  # QK^T + PV, fwd
+    return 6.0 * n_mm * sum(lens) + 3.0 * attn
+
+
 def dominant_kernel_roofline(model, iters=20):
     """gate|up projection forward GEMM of one layer at the bench shape, timed with HIP events on the
     stream it is launched on (torch's current stream)."""
@@ -66,7 +99,7 @@ def dominant_kernel_roofline(model, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<NT, DMA ring 3, 8 waves, 256x128> gate|up + fused SwiGLU, M8192 N9728 K896",
+    return {"bound": "mfma", "kernel": "gemm_kernel<NT, LDS-DMA ring 2, 4 waves, 128x128x64> gate|up + fused SwiGLU, M8192 N9728 K896",
             "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4), "traffic": None}
@@ -128,6 +161,59 @@ def cpu_baseline(timeout_s=240):
                 "sample": f"oracle step did not finish within {timeout_s}s on this host"}
 
 
+def bench_qwen1p5b(a, world, rank, dev):
+    """Extra workload (not the BASELINE metric): same step loop on the configs[3]-shaped model."""
+    from slamkit_amd.model import UnitLM, UnitLMConfig
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    cfg = UnitLMConfig(base_model_name=W4["name"], vocab_size=W4["vocab"], max_tokens=W4["tokens"])
+    model = UnitLM(cfg, seed=0)
+    args = SLAMTrainingArguments(per_device_train_batch_size=1, gradient_accumulation_steps=1, learning_rate=5e-4,
+                                 max_grad_norm=0.5, logging_steps=0)
+    trainer = SLAMTrainer(model=model, args=args)
+    nb = 4
+    made = [synth_packed_batch(rank, i, dev) for i in range(nb)]
+    batches = [[m[0]] for m in made]
+    counts = [float((m[0]["labels"] != -100).sum()) for m in made]
+
+    def step(i):
+        trainer.optimizer_step(batches[i % nb], 5e-4, counts=(counts[i % nb], counts[i % nb]))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        toks = sum(counts[(a.warmup + i) % nb] for i in range(a.steps))
+        flops = sum(w4_flops_per_batch(made[(a.warmup + i) % nb][1]) for i in range(a.steps))
+        print(json.dumps({
+            "metric": "train tokens/sec (whole node), Qwen2.5-1.5B-shaped interleaved model ctx=2048 packed",
+            "value": round(world * toks / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[3]-shaped: 28 L, H 1536, 12/2 heads of 128, I 8960, vocab 152167, 16384 packed "
+                                   "tokens per micro-batch, random-init weights; full optimizer step",
+                       "parallelism": f"dp{world}", "final_loss": round(float(trainer._loss_acc) / max(1, trainer._loss_n), 4)},
+            "roofline": {"bound": "mfma", "step_tflops_per_gpu": round(flops / dt / 1e12, 1),
+                         "step_frac": round(flops / dt / PEAK_BF16, 4), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s"},
+        }), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +221,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-accum", type=int, default=1)
+    ap.add_argument("--workload", default="slam358m", choices=["slam358m", "qwen1p5b"],
+                    help="slam358m = BASELINE.json configs[1] (the headline metric); qwen1p5b = configs[3]-shaped extra")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -152,6 +240,9 @@ def main():
 
     from slamkit_amd.model import UnitLM, UnitLMConfig
     from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+
+    if a.workload == "qwen1p5b":
+        return bench_qwen1p5b(a, world, rank, dev)
 
     cfg = UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=V, max_tokens=B * T)
     model = UnitLM(cfg, seed=0)

@@ -28,6 +28,10 @@ KNOWN_BASE_CONFIGS = {
     "Qwen/Qwen2.5-0.5B": dict(num_hidden_layers=24, hidden_size=896, num_attention_heads=14, num_key_value_heads=2,
                               head_dim=64, intermediate_size=4864, rms_norm_eps=1e-6, rope_theta=1000000.0,
                               tie_word_embeddings=True, initializer_range=0.02),
+    # interleaved speech-text scale-up body (BASELINE.json configs[3]; dims restated in SURVEY.md §8a-note)
+    "Qwen/Qwen2.5-1.5B": dict(num_hidden_layers=28, hidden_size=1536, num_attention_heads=12, num_key_value_heads=2,
+                              head_dim=128, intermediate_size=8960, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                              tie_word_embeddings=True, initializer_range=0.02),
 }
 
 
