@@ -133,6 +133,49 @@ SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* vo
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
+// Column-tile fragment assignment for 16-byte epilogue accesses: fragment fn of a wave's 64-column block
+// takes, for MFMA row i, the tile row frag_row(fn, i) = 32(fn>>1) + 8(i>>2) + 4(fn&1) + (i&3), so that the
+// fragments fn = 2q, 2q+1 of a lane (rows i = 4g..4g+3 of each) are the 8 CONSECUTIVE output columns
+// 32q + 8g .. +7 (half the store / bias / residual instructions of the 4-column layout). The tile rows stay
+// in natural order in LDS (a permuted DMA source order put rows r and r+8 into one request: same L2
+// channel for row strides of 9728 B, -12 % on the K=4864 shape); instead the chunk swizzle of the column
+// tile is keyed for this row pattern: a ds_read_b128 lane group holds rows {8a + b : a in {0,3} or {1,2}} of
+// one chunk, and key_c(r) = (2a + h) ^ [a in {1,2}] with a = (r>>3)&3, h = (r>>1)&1 gives its 16 lanes 16
+// distinct 16-byte slots.
+SLAM_DEVICE int lds_swz_key_c(int row) {
+  const int a = (row >> 3) & 3, h = (row >> 1) & 1;
+  return ((a << 1) | h) ^ ((a ^ (a >> 1)) & 1);
+}
+SLAM_DEVICE int perm64(int v) {
+  const int fn = v >> 4, i = v & 15;
+  return ((fn >> 1) << 5) | ((i >> 2) << 3) | ((fn & 1) << 2) | (i & 3);
+}
+// CMODE 1: the same fragment assignment obtained by permuting the DMA SOURCE rows instead (LDS row v of a
+// 64-row block holds tile row perm64(v); LDS layout, swizzle and reads as in the 4-column layout)
+template <int THREADS, int ROWS>
+SLAM_DEVICE void glds_offsets_perm(int ld, int nrows, int row0, int tid, uint32_t* voff) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
+    int P = i * THREADS + tid;
+    int row = P >> 3, cs = P & 7;
+    int c = cs ^ lds_swz_key(row);
+    int gr = row0 + (row & ~63) + perm64(row & 63);
+    gr = gr < nrows ? gr : nrows - 1;
+    voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
+  }
+}
+template <int THREADS, int ROWS>
+SLAM_DEVICE void glds_offsets_ckey(int ld, int nrows, int row0, int tid, uint32_t* voff) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
+    int P = i * THREADS + tid;
+    int row = P >> 3, cs = P & 7;
+    int c = cs ^ lds_swz_key_c(row);
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
+  }
+}
 template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const uint32_t* voff, int wave,
                            uint32_t tile_lds) {
@@ -166,7 +209,7 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 //             BMT = 256 (8 waves as 4x2 of 64x64): 256x128 tile, one block per CU, 33 % fewer L2->LDS bytes
 //             per flop - at ~1 PFLOP/s the 128x128 tile already pulls ~15 TB/s through the L2.
 template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4,
-          int BMT = 128>
+          int BMT = 128, int CMODE = 0 /* column-tile fragment assignment: 0 = 4-column, 1 = 8-column by DMA row order, 2 = 8-column by re-keyed swizzle */>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool GLDS = NSTAGE > 0;
@@ -174,6 +217,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   constexpr int WMN = BMT / 64, WNN = WAVES / WMN;  // wave grid
   constexpr int NF = 8 / WNN;                        // 16-column fragments per wave
   constexpr int A_BYTES = BMT * 128, STAGE = A_BYTES + TILE_BYTES;
+  constexpr bool PERM = CMODE != 0;  // 16-byte epilogue accesses (see lds_swz_key_c)
+  static_assert(!PERM || (GLDS && !(TA && TB) && !F32OUT && NF == 4), "8-column layout: NT DMA kernel, bf16 out, 4 waves");
   static_assert((WAVES == 4 && BMT == 128) || (WAVES == 8 && NSTAGE > 0), "8-wave blocks exist for the DMA ring only");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -220,6 +265,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   const int a_base = (wn * NF * 16 + l15) * 128;  // a-operand = column (B) tile
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
+  // PERM: a-operand lane (l15, g) of fragment fn reads tile row wn*64 + frag_row(fn, l15); its swizzle key
+  // depends on l15 only
+  const int kc_lane = lds_swz_key_c(((l15 >> 2) << 3) | (l15 & 3));
+  const int a_base_p = (wn * 64 + ((l15 >> 2) << 3) + (l15 & 3)) * 128;
   auto compute = [&](int s) {
     const char* At = smem + s * STAGE;
     const char* Bt = At + A_BYTES;
@@ -228,8 +277,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
       const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
       uint4 af[NF], bf[4];
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
-        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+      for (int f = 0; f < NF; ++f) {
+        if constexpr (CMODE == 2)
+          af[f] = *reinterpret_cast<const uint4*>(Bt + a_base_p + ((f >> 1) * 32 + (f & 1) * 4) * 128 + (((g + 4 * kk) ^ kc_lane) << 4));
+        else
+          af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+      }
 #pragma unroll
       for (int f = 0; f < 4; ++f)
         bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
@@ -281,7 +334,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
       glds_offsets_tr<THREADS, BN>(p.ldb, col0, tid, vob);
     } else {
       glds_offsets<THREADS, BMT>(p.lda, p.R, row0, tid, voa);
-      glds_offsets<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      if constexpr (CMODE == 2) glds_offsets_ckey<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      else if constexpr (CMODE == 1) glds_offsets_perm<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      else glds_offsets<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
     }
     constexpr int PT = (BMT + BN) * 8 / THREADS;  // DMAs per lane per tile
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -352,6 +407,106 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
 
   // ---- epilogue: lane holds C[m][n..n+3] for each (fm, fn); bias / residual loads are batched
   //      per row so they are all in flight together -------------------------------------------
+  if constexpr (PERM) {
+    // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
+    const int cw = col0 + wn * 64 + g * 8;  // + 32 q
+    uint4 bb4[2];
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) bb4[q] = *reinterpret_cast<const uint4*>(p.bias + cw + 32 * q);
+    }
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      const int m = row0 + wm * 64 + fm * 16 + l15;
+      const bool mok = m < p.R;
+      const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+      if (p.gu) {
+        // fused SwiGLU backward: acc = d(act)[m][c..c+7]; gate at gu[m][(c/32)*64 + c%32], up 32 columns later
+        bf16_t* grow = p.gu + (size_t)(mok ? m : 0) * (2 * p.Cn);
+        uint4 gg[2], uu[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = cw + 32 * q;
+          const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+          gg[q] = *reinterpret_cast<const uint4*>(gp);
+          uu[q] = *reinterpret_cast<const uint4*>(gp + 32);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = cw + 32 * q;
+          float gv[8], uv[8], dg[8], du[8];
+          unpack_bf16x8(gg[q], gv);
+          unpack_bf16x8(uu[q], uv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = acc[fm][2 * q + (e >> 2)][e & 3];
+            const float sg = fast_sigmoid(gv[e]);
+            du[e] = d * gv[e] * sg;
+            dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+          }
+          if (mok) {
+            bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<uint4*>(gp) = pack_bf16x8(dg);
+            *reinterpret_cast<uint4*>(gp + 32) = pack_bf16x8(du);
+          }
+        }
+        continue;
+      }
+      uint4 rr4[2];
+      if (p.resid) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rr4[q] = *reinterpret_cast<const uint4*>(p.resid + rowoff + cw + 32 * q);
+      }
+      float v[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] = acc[fm][2 * q + (e >> 2)][e & 3];
+        if (p.bias) {
+          float b[8];
+          unpack_bf16x8(bb4[q], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[q][e] += b[e];
+        }
+        if (p.resid) {
+          float r[8];
+          unpack_bf16x8(rr4[q], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[q][e] += r[e];
+        }
+      }
+      // fused RoPE: the wave's 64 columns are one head; q = 0 / 1 hold d and d + 32 of the same lane
+      if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
+        const float4* cp = reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + g * 8);
+        const float4* sp = reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + g * 8);
+        float cc[8], ss[8];
+        *reinterpret_cast<float4*>(cc) = cp[0]; *reinterpret_cast<float4*>(cc + 4) = cp[1];
+        *reinterpret_cast<float4*>(ss) = sp[0]; *reinterpret_cast<float4*>(ss + 4) = sp[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x1 = v[0][e], x2 = v[1][e];
+          v[0][e] = x1 * cc[e] - x2 * ss[e];
+          v[1][e] = x2 * cc[e] + x1 * ss[e];
+        }
+      }
+      if (mok) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q) = pack_bf16x8(v[q]);
+        // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up] = (q 0 | q 1) of the same lane
+        if (p.act) {
+          float a8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gt = acc[fm][e >> 2][e & 3], up = acc[fm][2 + (e >> 2)][e & 3];
+            a8[e] = gt * fast_sigmoid(gt) * up;
+          }
+          *reinterpret_cast<uint4*>(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8) = pack_bf16x8(a8);
+        }
+      }
+    }
+    return;
+  }
   uint2 bb[4];
   if (!F32OUT && p.bias) {
 #pragma unroll
@@ -620,12 +775,12 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
 
 static int g_group_rows = 4;  // step-level A/B on MI355X: 1 -> 35.5 ms, 4 -> 34.7, 8 -> 36.2, 16 -> 36.5
 
-template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128>
+template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128, int CMODE = 0>
 int launch(GemmArgs a, int splits, hipStream_t st) {
   constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * (BMT * 128 + TILE_BYTES);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT, CMODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -633,7 +788,7 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
   a.tiles_r = (a.R + BMT - 1) / BMT;
   a.group_rows = g_group_rows;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT><<<grid, WAVES * 64, lds, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT, CMODE><<<grid, WAVES * 64, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -658,6 +813,16 @@ namespace slam {
 
 // gemm_glds: 0 = register staging, 2/3/4 = LDS-DMA ring depth
 static int g_gemm_glds = 2;
+static int g_gemm_cmode = 1;
+void gemm_set_cmode(int m) { g_gemm_cmode = m; }
+// the default NT kernel (2-stage ring, 4 waves) in the selected column-tile layout
+static int launch_nt2(const GemmArgs& a, hipStream_t st) {
+  switch (g_gemm_cmode) {
+    case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);
+    case 2: return launch<false, false, false, 2, 4, 128, 2>(a, 1, st);
+    default: return launch<false, false, false, 2>(a, 1, st);
+  }
+}
 static int g_gemm_tn_dma = 1;
 void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
 void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
@@ -678,7 +843,7 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   const bool dma_ok = (K % BK == 0) && (N % BN == 0);
   const int mode = dma_ok ? g_gemm_glds : 0;
   switch (mode) {
-    case 2: return launch<false, false, false, 2>(a, 1, st);
+    case 2: return launch_nt2(a, st);
     case 3: return launch<false, false, false, 3>(a, 1, st);
     case 4: return launch<false, false, false, 4>(a, 1, st);
     case 323: return launch_k32<3>(a, st);
@@ -698,7 +863,7 @@ int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias
                  int rope_heads, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN, cs, sn, rope_heads};
-  return launch<false, false, false, 2>(a, 1, st);
+  return launch_nt2(a, st);
 }
 
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
@@ -707,7 +872,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
   // (the 256x128 / 3-stage variant, mode 163, was +16 % here before the grouped tile order; with it the
   //  128x128 kernel is faster again: 866 vs 782 TFLOP/s at M 8192, N 9728, K 896)
   if (g_gemm_glds == 163) return launch<false, false, false, 3, 8, 256>(a, 1, st);
-  return launch<false, false, false, 2>(a, 1, st);
+  return launch_nt2(a, st);
 }
 
 // d(act)[M,N] = dY[M,K] Wt[N,K]^T is never stored: gu [M,2N] (32-column gate/up blocks) is rewritten in
@@ -715,7 +880,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
   GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  return launch<false, false, false, 2>(a, 1, st);
+  return launch_nt2(a, st);
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+resid[M,K]); contraction over N.
