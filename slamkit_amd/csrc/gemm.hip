@@ -760,6 +760,166 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k32_kernel(GemmArgs p) {
 template <int NSTAGE>
 int launch_k32(GemmArgs a, hipStream_t st);
 
+// ---- wgrad with balanced K-splitting ----------------------------------------------------------------
+// dW[R][Cn] (fp32) (+)= A^T B with A [Kc][R], B [Kc][Cn] (both stored contraction-major), for the
+// DMA-eligible shapes. Equal K-splits of every tile leave the 512 block slots (2 per CU) badly filled when
+// tiles x splits is just above a multiple of 512 (gate|up weight: 532 tiles x 2 = 1064 blocks = three rounds
+// of work for 2.08 rounds of blocks). Here the tiles are cut in two groups inside ONE launch:
+//   A: the first T_A tiles, S_A pieces each, T_A*S_A a multiple of 512 (or <= 512): full rounds whose
+//      co-running blocks walk the contraction in lockstep and share operand slices in L2;
+//   B: the remaining T_B < 512/S_A tiles cut into many short pieces (S_B = up to 16) that fill the slots
+//      once more for a fraction of a round.
+// (A stream-K run-length decomposition balances even better on paper but skews the K positions of
+//  co-running blocks: no L2 sharing, 2.2 GB of operand traffic per launch, -40 %.)
+// Pieces of an unsplit tile accumulate straight into dW; split tiles write fp32 partial tiles to slabs and
+// reduce_bal_kernel adds them in piece order: no atomics, the same bits every run.
+struct BalArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* dW;
+  float* wsA;  // [S_A][R][Cn]            (S_A > 1)
+  float* wsB;  // [S_B][T_B][128 x 128]
+  int lda, ldb, ldc;
+  int tiles_r, tiles_c, KS, group_rows;
+  int T_A, S_A, per_A, T_B, S_B, per_B, nA;
+  int accumulate;
+  size_t slab_stride;
+};
+SLAM_DEVICE void bal_tile_rc(int t, int tiles_r, int tiles_c, int group_rows, int& tr_, int& tc_) {
+  const int GR = group_rows > 0 ? group_rows : 1;
+  const int per_group = GR * tiles_c;
+  const int grp = t / per_group, in = t - grp * per_group;
+  const int rows_here = min(GR, tiles_r - grp * GR);
+  tc_ = in / rows_here;
+  tr_ = grp * GR + in - tc_ * rows_here;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bal_kernel(BalArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  int t, ks0, ks1, stride;
+  float* dst;
+  bool direct = false;
+  {
+    int b = blockIdx.x;
+    if (b < p.nA) {
+      const int z = b / p.T_A, idx = b - z * p.T_A;
+      // block b runs on XCD b % 8: give each XCD a contiguous run of tiles (T_A is a multiple of 8 when split)
+      const int xcd = idx & 7, i8 = idx >> 3, q = p.T_A >> 3, r = p.T_A & 7;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i8;
+      ks0 = z * p.per_A;
+      ks1 = min(p.KS, ks0 + p.per_A);
+      int tr_, tc_;
+      bal_tile_rc(t, p.tiles_r, p.tiles_c, p.group_rows, tr_, tc_);
+      direct = p.S_A == 1;
+      dst = (direct ? p.dW : p.wsA + (size_t)z * p.slab_stride) + (size_t)tr_ * 128 * p.ldc + tc_ * 128;
+      stride = p.ldc;
+    } else {
+      b -= p.nA;
+      const int z = b / p.T_B, idx = b - z * p.T_B;
+      t = p.T_A + idx;
+      ks0 = z * p.per_B;
+      ks1 = min(p.KS, ks0 + p.per_B);
+      dst = p.wsB + ((size_t)z * p.T_B + idx) * (128 * 128);
+      stride = 128;
+    }
+  }
+  int tr_, tc_;
+  bal_tile_rc(t, p.tiles_r, p.tiles_c, p.group_rows, tr_, tc_);
+  const int nk = ks1 - ks0;
+  const int trk = (l15 >> 2) | ((g & 1) << 2);
+  const int tr_lane = (g * 8 + (l15 >> 2)) * 256 + (l15 & 3) * 8;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t voa[4], vob[4];
+  glds_offsets_tr<256, 128>(p.lda, tr_ * 128, tid, voa);
+  glds_offsets_tr<256, 128>(p.ldb, tc_ * 128, tid, vob);
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int k) {
+    const size_t k0 = (size_t)(ks0 + k) * BK;
+    const uint32_t st = lds0 + (uint32_t)((k & 1) * STAGE_BYTES);
+    glds_tile<256, 128>(p.A + k0 * p.lda, voa, wv, st);
+    glds_tile<256, 128>(p.B + k0 * p.ldb, vob, wv, st + TILE_BYTES);
+  };
+  if (nk > 0) issue(0);
+  for (int k = 0; k < nk; ++k) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (k + 1 < nk) issue(k + 1);
+    const char* At = smem + (k & 1) * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[4], bf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const char* pa = Bt + tr_lane + kk * 32 * 256 + (((wn * 4 + f) ^ trk) << 5);
+        uint2 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * 256);
+        af[f] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const char* pbp = At + tr_lane + kk * 32 * 256 + (((wm * 4 + f) ^ trk) << 5);
+        uint2 b0 = lds_tr_read(pbp), b1 = lds_tr_read(pbp + 4 * 256);
+        bf[f] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+      }
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+    }
+  }
+  const bool add = direct && p.accumulate;
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    float* row = dst + (size_t)(wm * 64 + fm * 16 + l15) * stride + wn * 64 + g * 4;
+    float4 old[4];
+    if (add) {
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) old[fn] = *reinterpret_cast<const float4*>(row + fn * 16);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      f32x4_t v = acc[fm][fn];
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
+      *reinterpret_cast<float4*>(row + fn * 16) = o;
+    }
+  }
+}
+
+// dW tile t (+)= its pieces in order; grid (16, tiles), thread = 4 consecutive columns
+__global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actual, int SB_actual) {
+  const int t = blockIdx.y;
+  if (t < p.T_A && p.S_A == 1) return;  // accumulated in place by the GEMM
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int r = e >> 7, c = e & 127;
+  int tr_, tc_;
+  bal_tile_rc(t, p.tiles_r, p.tiles_c, p.group_rows, tr_, tc_);
+  const size_t off = (size_t)(tr_ * 128 + r) * p.ldc + tc_ * 128 + c;
+  float4 s = p.accumulate ? *reinterpret_cast<const float4*>(p.dW + off) : make_float4(0, 0, 0, 0);
+  if (t < p.T_A) {
+    for (int k = 0; k < SA_actual; ++k) {
+      float4 v = *reinterpret_cast<const float4*>(p.wsA + (size_t)k * p.slab_stride + off);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  } else {
+    const float* src = p.wsB + (size_t)(t - p.T_A) * (128 * 128) + e;
+    const size_t zs = (size_t)p.T_B * (128 * 128);
+    for (int k = 0; k < SB_actual; ++k) {
+      float4 v = *reinterpret_cast<const float4*>(src + k * zs);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  *reinterpret_cast<float4*>(p.dW + off) = s;
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
                                      int splits, int accumulate) {
@@ -906,14 +1066,85 @@ int gemm_tn_splits(int M, int N, int K) {
   if (s < 1) s = 1;
   return s;
 }
+// balanced plan for the DMA-eligible shapes (see gemm_tn_bal_kernel)
+static int g_tn_balanced = 1;
+void gemm_set_tn_streamk(int on) { g_tn_balanced = on; }
+static const int BAL_SLOTS = 512;  // 2 blocks per CU on the 256-CU MI355X
+struct BalPlan { int T_A, S_A, per_A, SA_act, T_B, S_B, per_B, SB_act; };
+static bool tn_bal_ok(int M, int N, int K) {
+  return g_tn_balanced && g_gemm_tn_dma == 1 && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
+}
+static BalPlan tn_bal_plan(int M, int N, int K) {
+  const int T = (N / BM) * (K / BN), KS = M / BK;
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  const int OVH = 3;  // K-steps' worth of prologue + epilogue per piece (estimate used to choose between plans)
+  BalPlan best{};
+  int best_cost = 1 << 30;
+  auto consider = [&](int S, int T_A) {
+    if (S < 1 || S > 8 || S > KS || T_A < 0 || T_A > T) return;
+    BalPlan pl{};
+    pl.T_A = T_A; pl.S_A = S; pl.per_A = cdiv(KS, S); pl.SA_act = T_A ? cdiv(KS, pl.per_A) : 0;
+    pl.T_B = T - T_A;
+    int cost = T_A ? cdiv(T_A * pl.SA_act, BAL_SLOTS) * (pl.per_A + OVH) : 0;
+    if (pl.T_B) {
+      int sb = BAL_SLOTS / pl.T_B;
+      if (sb > 16) sb = 16;
+      if (sb < 1) sb = 1;
+      if (sb > KS) sb = KS;
+      pl.S_B = sb; pl.per_B = cdiv(KS, sb); pl.SB_act = cdiv(KS, pl.per_B);
+      cost += cdiv(pl.T_B * pl.SB_act, BAL_SLOTS) * (pl.per_B + OVH);
+    }
+    // slab traffic (written once, read once) in K-step units: ~0.5 K-steps per MB at ~5 TB/s
+    const double slab_mb = ((pl.S_A > 1 ? (double)pl.SA_act * pl.T_A : 0.0) + (double)pl.SB_act * pl.T_B) * (128 * 128 * 4) / 1e6;
+    cost += (int)(0.5 * slab_mb);
+    if (cost < best_cost) { best_cost = cost; best = pl; }
+  };
+  for (int S = 1; S <= 8; ++S) {
+    consider(S, T);                                                  // everything in equal pieces
+    int full = (T * S / BAL_SLOTS) * BAL_SLOTS / S;                  // tiles that make whole rounds
+    if (S > 1) full &= ~7;
+    if (full > 0 && full < T) consider(S, full);
+  }
+  return best;
+}
 size_t gemm_tn_workspace_bytes(int M, int N, int K) {
-  return (size_t)gemm_tn_splits(M, N, K) * N * K * sizeof(float);
+  size_t split = (size_t)gemm_tn_splits(M, N, K) * N * K * sizeof(float);
+  if ((N % BM == 0) && (K % BN == 0) && (M % BK == 0)) {
+    BalPlan pl = tn_bal_plan(M, N, K);
+    size_t bal = ((pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0) + (size_t)pl.SB_act * pl.T_B * 128 * 128) * sizeof(float);
+    if (bal > split) split = bal;
+  }
+  return split;
 }
 
 // dW[N,K] (fp32) (+)= dY[M,N]^T X[M,K]; contraction over M; split-K partials in `ws`.
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
             int ldx, float* ws, hipStream_t st) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
+  if (tn_bal_ok(M, N, K)) {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bal_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    const BalPlan pl = tn_bal_plan(M, N, K);
+    BalArgs a{};
+    a.A = dY; a.B = X; a.dW = dW; a.lda = ldy; a.ldb = ldx; a.ldc = K;
+    a.tiles_r = N / BM; a.tiles_c = K / BN; a.KS = M / BK; a.group_rows = g_group_rows;
+    a.T_A = pl.T_A; a.S_A = pl.S_A; a.per_A = pl.per_A; a.T_B = pl.T_B; a.S_B = pl.S_B; a.per_B = pl.per_B;
+    a.nA = pl.T_A * pl.SA_act;
+    a.accumulate = accumulate;
+    a.slab_stride = (size_t)N * K;
+    a.wsA = ws;
+    a.wsB = ws + (pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0);
+    const int nblk = a.nA + pl.T_B * pl.SB_act;
+    gemm_tn_bal_kernel<<<nblk, 256, 2 * STAGE_BYTES, st>>>(a);
+    if (pl.S_A > 1 || pl.T_B > 0)
+      reduce_bal_kernel<<<dim3(16, a.tiles_r * a.tiles_c), 256, 0, st>>>(a, pl.SA_act, pl.SB_act);
+    return (int)hipGetLastError();
+  }
   int splits = gemm_tn_splits(M, N, K);
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
