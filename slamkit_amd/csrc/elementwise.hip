@@ -9,11 +9,12 @@
 
 namespace {
 
-constexpr int MAXC = 4;  // chunks of 8 per lane -> hidden <= 2048
+constexpr int MAXC_LIMIT = 4;  // chunks of 8 per lane -> hidden <= 2048 (kernels are instantiated for 1..4)
 
 // ------------------------------------------------------------------------------------------
 // RMSNorm forward: y = bf16( x * rsqrt(mean(x^2)+eps) * w ), fp32 math, rstd saved.
 // Algorithmic traffic: 4 B/element (read bf16 + write bf16).
+template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd,
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 // RMSNorm backward. dx = rstd*(dy*w - xhat*mean(dy*w*xhat)) (+ dres); dw partial per block.
 // Each wave walks rows wave, wave+4*gridDim.. accumulating its dw slice in registers.
 // Algorithmic traffic: 6 B/element (+2 with the fused residual-gradient add).
+template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
                                                           const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w,
@@ -80,10 +82,32 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     int c = lane + 64 * i;
     if (c < nch) unpack_bf16x8(wr[c], wv[i]);
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  // software-pipelined over rows: the next row's loads are in flight while this row is reduced
+  auto load_row = [&](int row, uint4* rx, uint4* rdy, uint4* rdr) {
     const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * H);
     const uint4* dyr = reinterpret_cast<const uint4*>(dy + (size_t)row * H);
-    const float r = rstd[row];
+    const uint4* drr = dres ? reinterpret_cast<const uint4*>(dres + (size_t)row * H) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+        rx[i] = xr[c];
+        rdy[i] = dyr[c];
+        if (drr) rdr[i] = drr[c];
+      }
+    }
+  };
+  const int rstep = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  uint4 cx[MAXC], cdy[MAXC], cdr[MAXC];
+  float cr = 0.f;
+  if (row < M) { load_row(row, cx, cdy, cdr); cr = rstd[row]; }
+  for (; row < M; row += rstep) {
+    uint4 nx[MAXC], ndy[MAXC], ndr[MAXC];
+    float nr = 0.f;
+    const int nrow = row + rstep;
+    if (nrow < M) { load_row(nrow, nx, ndy, ndr); nr = rstd[nrow]; }
+    const float r = cr;
     float xh[MAXC][8], gy[MAXC][8];
     float dot = 0.f;
 #pragma unroll
@@ -91,8 +115,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       int c = lane + 64 * i;
       if (c < nch) {
         float fx[8], fd[8];
-        unpack_bf16x8(xr[c], fx);
-        unpack_bf16x8(dyr[c], fd);
+        unpack_bf16x8(cx[i], fx);
+        unpack_bf16x8(cdy[i], fd);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[i][j] = fx[j] * r;
@@ -104,7 +128,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
     dot = wave_sum(dot) / (float)H;
     uint4* dxr = reinterpret_cast<uint4*>(dx + (size_t)row * H);
-    const uint4* drr = dres ? reinterpret_cast<const uint4*>(dres + (size_t)row * H) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       int c = lane + 64 * i;
@@ -112,15 +135,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = r * (gy[i][j] - xh[i][j] * dot);
-        if (drr) {
+        if (dres) {
           float a[8];
-          unpack_bf16x8(drr[c], a);
+          unpack_bf16x8(cdr[i], a);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += a[j];
         }
         dxr[c] = pack_bf16x8(o);
       }
     }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { cx[i] = nx[i]; cdy[i] = ndy[i]; cdr[i] = ndr[i]; }
+    cr = nr;
   }
   // cross-wave reduction of the dw partials, then one row of dw_part per block
 #pragma unroll
@@ -707,8 +733,13 @@ namespace slam {
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st) {
-  if ((H & 7) || H > MAXC * 512) return -1;
-  rmsnorm_fwd_kernel<<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps);
+  if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
+  switch ((H / 8 + 63) / 64) {
+    case 1: rmsnorm_fwd_kernel<1><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    case 2: rmsnorm_fwd_kernel<2><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    case 3: rmsnorm_fwd_kernel<3><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    default: rmsnorm_fwd_kernel<4><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+  }
   LAUNCH_RET();
 }
 
@@ -716,9 +747,14 @@ int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {
-  if ((H & 7) || H > MAXC * 512) return -1;
+  if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
-  rmsnorm_bwd_kernel<<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);
+  switch ((H / 8 + 63) / 64) {
+    case 1: rmsnorm_bwd_kernel<1><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    case 2: rmsnorm_bwd_kernel<2><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    case 3: rmsnorm_bwd_kernel<3><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    default: rmsnorm_bwd_kernel<4><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+  }
   if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0);  // dw == null: caller finishes later
   LAUNCH_RET();
 }

@@ -46,7 +46,15 @@ struct GemmArgs {
   const float* rope_sin;
   int rope_heads;
   int group_rows;  // tile rasterisation group height (0/1 = plain row-major)
+  int nt_store;    // streaming (non-temporal) output stores: large outputs must not evict the operand panels from L2
 };
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+SLAM_DEVICE void st_out(bf16_t* ptr, const uint4& v, int nt) {
+  u32x4_t w = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(ptr));
+  else *reinterpret_cast<u32x4_t*>(ptr) = w;
+}
 
 SLAM_DEVICE uint32_t comp4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 SLAM_DEVICE uint4 sel4(bool ok, const uint4& v) {
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
       if (mok) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q) = pack_bf16x8(v[q]);
+          st_out(reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q, pack_bf16x8(v[q]), p.nt_store);
         // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up] = (q 0 | q 1) of the same lane
         if (p.act) {
           float a8[8];
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
             const float gt = acc[fm][e >> 2][e & 3], up = acc[fm][2 + (e >> 2)][e & 3];
             a8[e] = gt * fast_sigmoid(gt) * up;
           }
-          *reinterpret_cast<uint4*>(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8) = pack_bf16x8(a8);
+          st_out(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, pack_bf16x8(a8), p.nt_store);
         }
       }
     }
@@ -933,7 +941,8 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
-static int g_group_rows = 4;  // step-level A/B on MI355X: 1 -> 35.5 ms, 4 -> 34.7, 8 -> 36.2, 16 -> 36.5
+static int g_nt_store = 0;
+static int g_group_rows = 3;  // step-level A/B on MI355X (same box): 1 -> 32.4 ms, 2 -> 31.2, 3 -> 31.2, 4 -> 31.5, 8 -> 32.8
 
 template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128, int CMODE = 0>
 int launch(GemmArgs a, int splits, hipStream_t st) {
@@ -947,6 +956,7 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
   }
   a.tiles_r = (a.R + BMT - 1) / BMT;
   a.group_rows = g_group_rows;
+  a.nt_store = g_nt_store;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
   gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT, CMODE><<<grid, WAVES * 64, lds, st>>>(a);
   return (int)hipGetLastError();
@@ -987,6 +997,7 @@ static int g_gemm_tn_dma = 1;
 void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
 void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
 void gemm_set_group_rows(int g) { g_group_rows = g; }
+void gemm_set_nt_store(int on) { g_nt_store = on; }
 
 static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
   if (R <= 0 || Cn <= 0 || Kc <= 0) return -1;
