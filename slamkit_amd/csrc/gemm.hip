@@ -212,6 +212,108 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
   }
 }
 
+// Epilogue of the 8-column layout (CMODE 1 / 2): lane (l15, g) of wave (wm, wn) holds C[m][cw + 32q .. +7] for
+// q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout. Fused: bias, residual, RoPE, SwiGLU fwd / bwd.
+SLAM_DEVICE void epilogue8(const GemmArgs& p, const f32x4_t (&acc)[4][4], int row0, int col0, int wm, int wn, int l15, int g) {
+  // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
+  const int cw = col0 + wn * 64 + g * 8;  // + 32 q
+  uint4 bb4[2];
+  if (p.bias) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bb4[q] = *reinterpret_cast<const uint4*>(p.bias + cw + 32 * q);
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + wm * 64 + fm * 16 + l15;
+    const bool mok = m < p.R;
+    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+    if (p.gu) {
+      // fused SwiGLU backward: acc = d(act)[m][c..c+7]; gate at gu[m][(c/32)*64 + c%32], up 32 columns later
+      bf16_t* grow = p.gu + (size_t)(mok ? m : 0) * (2 * p.Cn);
+      uint4 gg[2], uu[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cw + 32 * q;
+        const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+        gg[q] = *reinterpret_cast<const uint4*>(gp);
+        uu[q] = *reinterpret_cast<const uint4*>(gp + 32);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cw + 32 * q;
+        float gv[8], uv[8], dg[8], du[8];
+        unpack_bf16x8(gg[q], gv);
+        unpack_bf16x8(uu[q], uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = acc[fm][2 * q + (e >> 2)][e & 3];
+          const float sg = fast_sigmoid(gv[e]);
+          du[e] = d * gv[e] * sg;
+          dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+        }
+        if (mok) {
+          bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+          *reinterpret_cast<uint4*>(gp) = pack_bf16x8(dg);
+          *reinterpret_cast<uint4*>(gp + 32) = pack_bf16x8(du);
+        }
+      }
+      continue;
+    }
+    uint4 rr4[2];
+    if (p.resid) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) rr4[q] = *reinterpret_cast<const uint4*>(p.resid + rowoff + cw + 32 * q);
+    }
+    float v[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[q][e] = acc[fm][2 * q + (e >> 2)][e & 3];
+      if (p.bias) {
+        float b[8];
+        unpack_bf16x8(bb4[q], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] += b[e];
+      }
+      if (p.resid) {
+        float r[8];
+        unpack_bf16x8(rr4[q], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] += r[e];
+      }
+    }
+    // fused RoPE: the wave's 64 columns are one head; q = 0 / 1 hold d and d + 32 of the same lane
+    if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
+      const float4* cp = reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + g * 8);
+      const float4* sp = reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + g * 8);
+      float cc[8], ss[8];
+      *reinterpret_cast<float4*>(cc) = cp[0]; *reinterpret_cast<float4*>(cc + 4) = cp[1];
+      *reinterpret_cast<float4*>(ss) = sp[0]; *reinterpret_cast<float4*>(ss + 4) = sp[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x1 = v[0][e], x2 = v[1][e];
+        v[0][e] = x1 * cc[e] - x2 * ss[e];
+        v[1][e] = x2 * cc[e] + x1 * ss[e];
+      }
+    }
+    if (mok) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        st_out(reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q, pack_bf16x8(v[q]), p.nt_store);
+      // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up] = (q 0 | q 1) of the same lane
+      if (p.act) {
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gt = acc[fm][e >> 2][e & 3], up = acc[fm][2 + (e >> 2)][e & 3];
+          a8[e] = gt * fast_sigmoid(gt) * up;
+        }
+        st_out(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, pack_bf16x8(a8), p.nt_store);
+      }
+    }
+  }
+}
+
 // WAVES = 4: 2x2 waves of 64x64, 2 blocks/CU; WAVES = 8: 2x4 waves of 64x32, one block per CU with a
 // deeper DMA ring (same 2 waves per SIMD, more latency budget per tile).
 //             BMT = 256 (8 waves as 4x2 of 64x64): 256x128 tile, one block per CU, 33 % fewer L2->LDS bytes
@@ -232,7 +334,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WNN, wn = wave % WNN;
   const int l15 = lane & 15, g = lane >> 4;
-
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
   // (bijective for any tile count).
   const int nblk = p.tiles_r * p.tiles_c;
@@ -416,103 +517,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
   // ---- epilogue: lane holds C[m][n..n+3] for each (fm, fn); bias / residual loads are batched
   //      per row so they are all in flight together -------------------------------------------
   if constexpr (PERM) {
-    // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
-    const int cw = col0 + wn * 64 + g * 8;  // + 32 q
-    uint4 bb4[2];
-    if (p.bias) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) bb4[q] = *reinterpret_cast<const uint4*>(p.bias + cw + 32 * q);
-    }
-#pragma unroll
-    for (int fm = 0; fm < 4; ++fm) {
-      const int m = row0 + wm * 64 + fm * 16 + l15;
-      const bool mok = m < p.R;
-      const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
-      if (p.gu) {
-        // fused SwiGLU backward: acc = d(act)[m][c..c+7]; gate at gu[m][(c/32)*64 + c%32], up 32 columns later
-        bf16_t* grow = p.gu + (size_t)(mok ? m : 0) * (2 * p.Cn);
-        uint4 gg[2], uu[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int c = cw + 32 * q;
-          const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
-          gg[q] = *reinterpret_cast<const uint4*>(gp);
-          uu[q] = *reinterpret_cast<const uint4*>(gp + 32);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int c = cw + 32 * q;
-          float gv[8], uv[8], dg[8], du[8];
-          unpack_bf16x8(gg[q], gv);
-          unpack_bf16x8(uu[q], uv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = acc[fm][2 * q + (e >> 2)][e & 3];
-            const float sg = fast_sigmoid(gv[e]);
-            du[e] = d * gv[e] * sg;
-            dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
-          }
-          if (mok) {
-            bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
-            *reinterpret_cast<uint4*>(gp) = pack_bf16x8(dg);
-            *reinterpret_cast<uint4*>(gp + 32) = pack_bf16x8(du);
-          }
-        }
-        continue;
-      }
-      uint4 rr4[2];
-      if (p.resid) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) rr4[q] = *reinterpret_cast<const uint4*>(p.resid + rowoff + cw + 32 * q);
-      }
-      float v[2][8];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[q][e] = acc[fm][2 * q + (e >> 2)][e & 3];
-        if (p.bias) {
-          float b[8];
-          unpack_bf16x8(bb4[q], b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[q][e] += b[e];
-        }
-        if (p.resid) {
-          float r[8];
-          unpack_bf16x8(rr4[q], r);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[q][e] += r[e];
-        }
-      }
-      // fused RoPE: the wave's 64 columns are one head; q = 0 / 1 hold d and d + 32 of the same lane
-      if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
-        const float4* cp = reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + g * 8);
-        const float4* sp = reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + g * 8);
-        float cc[8], ss[8];
-        *reinterpret_cast<float4*>(cc) = cp[0]; *reinterpret_cast<float4*>(cc + 4) = cp[1];
-        *reinterpret_cast<float4*>(ss) = sp[0]; *reinterpret_cast<float4*>(ss + 4) = sp[1];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x1 = v[0][e], x2 = v[1][e];
-          v[0][e] = x1 * cc[e] - x2 * ss[e];
-          v[1][e] = x2 * cc[e] + x1 * ss[e];
-        }
-      }
-      if (mok) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          st_out(reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q, pack_bf16x8(v[q]), p.nt_store);
-        // fused SwiGLU: this wave's 64 columns are [32 gate | 32 up] = (q 0 | q 1) of the same lane
-        if (p.act) {
-          float a8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float gt = acc[fm][e >> 2][e & 3], up = acc[fm][2 + (e >> 2)][e & 3];
-            a8[e] = gt * fast_sigmoid(gt) * up;
-          }
-          st_out(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, pack_bf16x8(a8), p.nt_store);
-        }
-      }
-    }
+    epilogue8(p, acc, row0, col0, wm, wn, l15, g);
     return;
   }
   uint2 bb[4];
@@ -637,6 +642,101 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
         }
       }
     }
+  }
+}
+
+// ---- persistent NT kernel -----------------------------------------------------------------------------
+// Same tile, ring, fragment layout (CMODE 1) and epilogue as gemm_kernel<NT, 2 stages, 4 waves>, but the grid
+// is the 512 block slots and each block walks tiles id, id + 512, ...: a retiring block holds its LDS and
+// registers until its output stores are acknowledged and its successor then starts with a cold prologue
+// (gate|up forward: 132 us of main loops, 159 us with the output stores). Here the first K-step of the next
+// tile is DMA'd into the free ring stage during the last K-step of the current one, so the fetch latency
+// and the store drain of a tile overlap with its epilogue.
+__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  auto tile_of = [&](int id, int& row0, int& col0) {
+    const int xcd = id & 7, idx = id >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    const int tc_ = in / rows_here;
+    row0 = (grp * GR + in - tc_ * rows_here) * BM;
+    col0 = tc_ * BN;
+  };
+  const int s0a = ((l15 >> 1) ^ (wn * 4)) & 7;
+  const int s0b = ((l15 >> 1) ^ (wm * 4)) & 7;
+  const int a_base = (wn * 64 + l15) * 128;
+  const int b_base = (wm * 64 + l15) * 128;
+
+  int cur = blockIdx.x;
+  if (cur >= nblk) return;
+  int row0, col0;
+  tile_of(cur, row0, col0);
+  uint32_t voa[4], vob[4];
+  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
+  glds_offsets_perm<256, 128>(p.ldb, p.Cn, col0, tid, vob);
+  int sbase = 0;  // ring stage of the current tile's K-step 0
+  {
+    const uint32_t st = lds0;
+    glds_tile<256, 128>(p.A, voa, wv, st);
+    glds_tile<256, 128>(p.B, vob, wv, st + TILE_BYTES);
+  }
+  while (true) {
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int next = cur + gridDim.x;
+    int nrow0 = 0, ncol0 = 0;
+    for (int t = 0; t < nk; ++t) {
+      wait_vmcnt<0>();  // this K-step's tile has landed (and, at t == 0, the previous tile's stores are out)
+      __syncthreads();
+      const int sidx = (sbase + t) & 1;
+      if (t + 1 < nk) {
+        const uint32_t st = lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES);
+        glds_tile<256, 128>(p.A + (t + 1) * BK, voa, wv, st);
+        glds_tile<256, 128>(p.B + (t + 1) * BK, vob, wv, st + TILE_BYTES);
+      } else if (next < nblk) {
+        // last K-step: the other stage is free; start the next tile's first K-step now
+        tile_of(next, nrow0, ncol0);
+        glds_offsets<256, 128>(p.lda, p.R, nrow0, tid, voa);
+        glds_offsets_perm<256, 128>(p.ldb, p.Cn, ncol0, tid, vob);
+        const uint32_t st = lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES);
+        glds_tile<256, 128>(p.A, voa, wv, st);
+        glds_tile<256, 128>(p.B, vob, wv, st + TILE_BYTES);
+      }
+      const char* At = smem + sidx * STAGE_BYTES;
+      const char* Bt = At + TILE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
+        uint4 af[4], bf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+      }
+    }
+    epilogue8(p, acc, row0, col0, wm, wn, l15, g);
+    if (next >= nblk) break;
+    cur = next; row0 = nrow0; col0 = ncol0;
+    sbase = (sbase + nk) & 1;
   }
 }
 
@@ -986,7 +1086,25 @@ static int g_gemm_glds = 2;
 static int g_gemm_cmode = 1;
 void gemm_set_cmode(int m) { g_gemm_cmode = m; }
 // the default NT kernel (2-stage ring, 4 waves) in the selected column-tile layout
-static int launch_nt2(const GemmArgs& a, hipStream_t st) {
+static int g_gemm_persist = 0;  // measured neutral at kernel and step level (30.26 vs 30.20 ms): kept selectable ("gemm_persist")
+void gemm_set_persist(int on) { g_gemm_persist = on; }
+static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
+  if (g_gemm_persist && g_gemm_cmode == 1 && a0.tiles_r * a0.tiles_c > 512) {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_persist_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    GemmArgs a = a0;
+    a.tiles_r = (a.R + BM - 1) / BM;
+    a.group_rows = g_group_rows;
+    a.nt_store = g_nt_store;
+    gemm_nt_persist_kernel<<<512, 256, 2 * STAGE_BYTES, st>>>(a);
+    return (int)hipGetLastError();
+  }
+  const GemmArgs& a = a0;
   switch (g_gemm_cmode) {
     case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);
     case 2: return launch<false, false, false, 2, 4, 128, 2>(a, 1, st);
