@@ -704,40 +704,56 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs p) {
       wait_vmcnt<0>();  // this K-step's tile has landed (and, at t == 0, the previous tile's stores are out)
       __syncthreads();
       const int sidx = (sbase + t) & 1;
-      if (t + 1 < nk) {
-        const uint32_t st = lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES);
-        glds_tile<256, 128>(p.A + (t + 1) * BK, voa, wv, st);
-        glds_tile<256, 128>(p.B + (t + 1) * BK, vob, wv, st + TILE_BYTES);
-      } else if (next < nblk) {
-        // last K-step: the other stage is free; start the next tile's first K-step now
-        tile_of(next, nrow0, ncol0);
-        glds_offsets<256, 128>(p.lda, p.R, nrow0, tid, voa);
-        glds_offsets_perm<256, 128>(p.ldb, p.Cn, ncol0, tid, vob);
-        const uint32_t st = lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES);
-        glds_tile<256, 128>(p.A, voa, wv, st);
-        glds_tile<256, 128>(p.B, vob, wv, st + TILE_BYTES);
+      // what the 8 DMA pieces of this K-step fetch: the next K-step of this tile, or (last K-step) the
+      // first K-step of the block's next tile into the stage that has just become free
+      const bf16_t* ga = p.A + (t + 1) * BK;
+      const bf16_t* gb = p.B + (t + 1) * BK;
+      if (t + 1 == nk) {
+        // (the very last K-step of the block has nothing to fetch: it re-fetches its own first K-step into
+        //  the free stage so that the loop body stays branch-free; drained before the block exits)
+        ga = p.A; gb = p.B;
+        if (next < nblk) {
+          tile_of(next, nrow0, ncol0);
+          glds_offsets<256, 128>(p.lda, p.R, nrow0, tid, voa);
+          glds_offsets_perm<256, 128>(p.ldb, p.Cn, ncol0, tid, vob);
+        }
       }
+      const uint32_t dstA = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES) + (uint32_t)wv * 1024u);
       const char* At = smem + sidx * STAGE_BYTES;
       const char* Bt = At + TILE_BYTES;
+      // all 16 fragment reads of the K-step first, then 8 groups of 4 MFMAs with ONE DMA piece issued
+      // between groups: the piece's issue slots sit in the shadow of the queued MFMAs instead of in front
+      // of the K-step (8 pieces back to back cost ~1k cycles before the first MFMA)
+      uint4 af[2][4], bf[2][4];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
-        uint4 af[4], bf[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
+        for (int f = 0; f < 4; ++f) af[kk][f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
 #pragma unroll
-        for (int f = 0; f < 4; ++f) bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-          for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+        for (int f = 0; f < 4; ++f) bf[kk][f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
       }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+#pragma unroll
+          for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[kk][fn], bf[kk][fm], acc[fm][fn]);
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const int i = kk * 4 + fm;  // pieces 0..3: row tile, 4..7: column tile; piece = 256 rows-chunks x 16 B
+            if (i < 4) glds16_sv(ga, voa[i], dstA + (uint32_t)(i * 4096));
+            else glds16_sv(gb, vob[i - 4], dstA + (uint32_t)(TILE_BYTES + (i - 4) * 4096));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
     }
     epilogue8(p, acc, row0, col0, wm, wn, l15, g);
     if (next >= nblk) break;
     cur = next; row0 = nrow0; col0 = ncol0;
     sbase = (sbase + nk) & 1;
   }
+  wait_vmcnt<0>();  // the trailing dummy fetch must not land in a successor block's LDS
 }
 
 // ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
