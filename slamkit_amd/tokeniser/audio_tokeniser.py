@@ -54,5 +54,7 @@ def tokeniser_factory(cfg) -> AudioTokeniser:
         from .unit_tokeniser import UnitTokeniser
         return UnitTokeniser(None, **params)
     if ttype == "interleave":
-        raise ValueError("interleaving tokeniser needs a hub text tokenizer + alignments (SURVEY.md §2 row 6: out of scope)")
+        from .interleaving_tokeniser import InterleavingTokeniser
+        params.pop("bos_eos_token_id", None)
+        return InterleavingTokeniser(None, **params)
     raise ValueError(f"Unknown tokeniser type: {ttype}")
