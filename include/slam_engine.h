@@ -103,6 +103,11 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
 
 /* Per-sequence log-likelihood sums of the last forward (UnitLM.log_likelihood :184-194 /
  * calc_nll, slamkit/utils/calculation_utils.py:5-29): ll_out, cnt_out fp32 [B] device. */
+/* Modality-restricted scoring (UnitLM.log_likelihood(ignore_tokens=...), unit_lm.py:185-188): columns whose byte
+ * in `mask` (device pointer to slam_padded_vocab(h) bytes, borrowed until reset with NULL) is non-zero are treated
+ * as -inf by the loss of every following slam_forward; a target inside the mask gives an infinite row loss. */
+int slam_set_logit_mask(SlamEngine* h, const uint8_t* mask);
+int32_t slam_padded_vocab(SlamEngine* h);
 int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, float* ll_out, float* cnt_out,
                     slam_stream_t stream);
 

@@ -224,10 +224,12 @@ def calc_nll(logits, target, mask, len_norm=True):
     return ll / mask.sum(dim=-1) if len_norm else ll
 
 
-def log_likelihood(cfg, sd, tokens: torch.Tensor, mean_nll: bool):
-    """UnitLM.log_likelihood, unit_lm.py:184-194 (ignore_tokens=None path)."""
+def log_likelihood(cfg, sd, tokens: torch.Tensor, mean_nll: bool, ignore_tokens=None):
+    """UnitLM.log_likelihood, unit_lm.py:184-194."""
     with torch.no_grad():
         logits = model_forward(cfg, sd, tokens)
+        if ignore_tokens is not None:
+            logits[:, :, ignore_tokens] = float("-inf")
         shifted_x = tokens[..., 1:].clone()
         shifted_logits = logits[..., :-1, :]
         shifted_x[shifted_x == cfg.pad_token_id] = -100

@@ -352,7 +352,8 @@ __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int B, in
 __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits,
                                                  const int64_t* __restrict__ labels,
                                                  const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
-                                                 float* __restrict__ row_loss, int B, int T, int Vp, int V) {
+                                                 float* __restrict__ row_loss, int B, int T, int Vp, int V,
+                                                 const uint8_t* __restrict__ colmask) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int M = B * T;
@@ -368,17 +369,25 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
   }
   float f[8];
   unpack_bf16x8(reinterpret_cast<const uint4*>(logits + (size_t)m * Vp)[lane], f);
+  // columns >= V (padding) and columns flagged in colmask (modality-restricted scoring: the reference sets
+  // those logits to -inf, unit_lm.py:187-188) are outside the softmax
+  bool on[8];
+  {
+    uint2 mk = colmask ? *reinterpret_cast<const uint2*>(colmask + lane * 8) : make_uint2(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) on[j] = (lane * 8 + j < V) && !(((j < 4 ? mk.x : mk.y) >> (8 * (j & 3))) & 0xff);
+  }
   float mx = -3.0e38f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (lane * 8 + j >= V) f[j] = -3.0e38f;
+    if (!on[j]) f[j] = -3.0e38f;
     mx = fmaxf(mx, f[j]);
   }
   mx = wave_max(mx);
   float e[8], s = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    e[j] = (lane * 8 + j < V) ? __expf(f[j] - mx) : 0.f;
+    e[j] = on[j] ? __expf(f[j] - mx) : 0.f;
     s += e[j];
   }
   s = wave_sum(s);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
   for (int j = 0; j < 8; ++j)
     if (lane * 8 + j == (int)tgt) tl = f[j];
   tl = wave_sum(tl);
-  if (lane == 0) row_loss[m] = lse - tl;
+  if (lane == 0) row_loss[m] = (colmask && colmask[tgt]) ? INFINITY : lse - tl;
   if (dl) {
     const float sc = 1.f / denom[0];
     const float inv = 1.f / s;
@@ -410,7 +419,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 __global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ logits,
                                                      const int64_t* __restrict__ labels,
                                                      const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
-                                                     float* __restrict__ row_loss, int B, int T, int Vp, int V) {
+                                                     float* __restrict__ row_loss, int B, int T, int Vp, int V,
+                                                     const uint8_t* __restrict__ colmask) {
   __shared__ float red_m[4], red_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.x;
@@ -430,16 +440,19 @@ __global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ 
   for (int c = tid; c < nch; c += 256) {
     float f[8];
     unpack_bf16x8(lr[c], f);
+    const uint2 mk = colmask ? *reinterpret_cast<const uint2*>(colmask + c * 8) : make_uint2(0, 0);
+    bool on[8];
     float cm = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (c * 8 + j >= V) f[j] = -3.0e38f;
+      on[j] = (c * 8 + j < V) && !(((j < 4 ? mk.x : mk.y) >> (8 * (j & 3))) & 0xff);
+      if (!on[j]) f[j] = -3.0e38f;
       cm = fmaxf(cm, f[j]);
     }
     const float nm = fmaxf(mx, cm);
     float cs = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cs += (c * 8 + j < V) ? __expf(f[j] - nm) : 0.f;
+    for (int j = 0; j < 8; ++j) cs += on[j] ? __expf(f[j] - nm) : 0.f;
     sm = sm * __expf(mx - nm) + cs;
     mx = nm;
   }
@@ -452,16 +465,18 @@ __global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int w = 0; w < 4; ++w) bs += red_s[w] * __expf(red_m[w] - bm);
   const float lse = bm + logf(bs);
-  if (tid == 0) row_loss[m] = lse - bf16_to_f32(logits[(size_t)m * Vp + tgt]);
+  if (tid == 0) row_loss[m] = (colmask && colmask[tgt]) ? INFINITY : lse - bf16_to_f32(logits[(size_t)m * Vp + tgt]);
   if (dl) {
     const float sc = 1.f / denom[0];
     for (int c = tid; c < nch; c += 256) {
       float f[8], o[8];
       unpack_bf16x8(lr[c], f);
+      const uint2 mk = colmask ? *reinterpret_cast<const uint2*>(colmask + c * 8) : make_uint2(0, 0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int col = c * 8 + j;
-        float pj = col < V ? __expf(f[j] - lse) : 0.f;
+        const bool onj = (col < V) && !(((j < 4 ? mk.x : mk.y) >> (8 * (j & 3))) & 0xff);
+        float pj = onj ? __expf(f[j] - lse) : 0.f;
         if (col == (int)tgt) pj -= 1.f;
         o[j] = pj * sc;
       }
@@ -829,12 +844,12 @@ int embed_bwd(const int64_t* ids, const bf16_t* dh, float* dE, int M, int H, int
 }
 
 int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
-                  float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st) {
+                  float* denom, float* loss, int B, int T, int Vp, int V, const uint8_t* colmask, hipStream_t st) {
   if (Vp < 512 || (Vp & 7) || V > Vp) return -1;
   int M = B * T;
   count_valid_kernel<<<1, 256, 0, st>>>(labels, B, T, num_items, denom);
-  if (Vp == 512) ce_kernel<<<(M + 3) / 4, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
-  else ce_big_kernel<<<M, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V);
+  if (Vp == 512) ce_kernel<<<(M + 3) / 4, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V, colmask);
+  else ce_big_kernel<<<M, 256, 0, st>>>(logits, labels, denom, dlogits, row_loss, B, T, Vp, V, colmask);
   loss_finish_kernel<<<1, 256, 0, st>>>(row_loss, M, denom, loss);
   LAUNCH_RET();
 }

@@ -61,6 +61,7 @@ struct SlamEngine {
   std::vector<LayerAct> la;
   bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
   int* embed_ws = nullptr;
+  const uint8_t* logit_mask = nullptr;  // optional [vpad] bytes: non-zero = column excluded from the softmax
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -355,7 +356,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
   h->have_loss = false;
   if (labels) {
     CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VP,
-                     d.vocab, st));
+                     d.vocab, h->logit_mask, st));
     CK((int)hipMemcpyAsync(loss_out, h->scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     h->have_loss = true;
   }
@@ -420,7 +421,10 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
-    if (l == 0 || (cb && ((L - l) % bl) == 0)) {
+    // bucket boundaries: every `bl` layers from the top, and after each of the last two layers so that the
+    // final all-reduce (exposed behind the end of backward) only carries layer 0 + the embedding
+    const bool boundary = cb && l > 0 && ((((L - l) % bl) == 0) || l <= 2);
+    if (l == 0 || boundary) {
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
       const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
@@ -429,7 +433,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, 1, st));
       fin_hi = l;
     }
-    if (cb && l > 0 && ((L - l) % bl) == 0) {
+    if (boundary) {
       cb(user, o.ln1, bucket_end - o.ln1);
       bucket_end = o.ln1;
     }
@@ -446,6 +450,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;
 }
+
+int slam_set_logit_mask(SlamEngine* h, const uint8_t* mask) {
+  if (!h) return SLAM_EINVAL;
+  h->logit_mask = mask;
+  return SLAM_OK;
+}
+int32_t slam_padded_vocab(SlamEngine* h) { return h ? h->vpad : 0; }
 
 int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, float* ll_out, float* cnt_out,
                     slam_stream_t stream) {
@@ -553,7 +564,7 @@ int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const floa
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
                           float* scratch2, int B, int T, int Vp, int V, slam_stream_t s) {
   return cross_entropy((const bf16_t*)logits, labels, num_items, (bf16_t*)dlogits, row_loss, scratch2, scratch2 + 1, B,
-                       T, Vp, V, (hipStream_t)s);
+                       T, Vp, V, nullptr, (hipStream_t)s);
 }
 size_t slam_op_embed_bwd_workspace(int M, int Vp) { return embed_bwd_workspace_ints(M, Vp) * sizeof(int); }
 int slam_op_embed_bwd(const int64_t* ids, const void* dh, float* dE, int M, int H, int Vp, int V, int pad_id, void* ws,

@@ -63,7 +63,7 @@ size_t embed_bwd_workspace_ints(int M, int Vp);
 int embed_bwd(const int64_t* ids, const bf16_t* dh, float* dE, int M, int H, int Vp, int V, int pad_id, int* ws,
               hipStream_t st);
 int cross_entropy(const bf16_t* logits, const int64_t* labels, double num_items, bf16_t* dlogits, float* row_loss,
-                  float* denom, float* loss, int B, int T, int Vp, int V, hipStream_t st);
+                  float* denom, float* loss, int B, int T, int Vp, int V, const uint8_t* colmask, hipStream_t st);
 int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float* ll, float* cnt, hipStream_t st);
 int copy_cols(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int ncols, hipStream_t st);
 int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st);

@@ -64,6 +64,8 @@ def load_library(path: Optional[str] = None):
         "slam_bind_workspace": (C.c_int, [vp, vp, sz, i64]),
         "slam_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
         "slam_backward": (C.c_int, [vp, f32, i32, BUCKET_CB, vp, vp]),
+        "slam_set_logit_mask": (C.c_int, [vp, vp]),
+        "slam_padded_vocab": (i32, [vp]),
         "slam_seq_loglik": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         "slam_scale_loss_rows": (C.c_int, [vp, vp, i32, i32, vp]),
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
@@ -200,6 +202,13 @@ class Engine:
             cb = BUCKET_CB(lambda _u, off, cnt: bucket_cb(int(off), int(cnt)))
         self._ck(self.lib.slam_backward(self.h, float(grad_scale), int(bucket_layers), cb, None,
                                         stream if stream is not None else current_stream_ptr()))
+
+    def set_logit_mask(self, mask_u8=None):
+        """mask_u8: uint8 device tensor of padded_vocab() bytes (non-zero = column outside the softmax) or None."""
+        self._ck(self.lib.slam_set_logit_mask(self.h, _ptr(mask_u8) if mask_u8 is not None else None))
+
+    def padded_vocab(self) -> int:
+        return int(self.lib.slam_padded_vocab(self.h))
 
     def seq_loglik(self, labels, B, T, ll_out, cnt_out, stream=None):
         self._ck(self.lib.slam_seq_loglik(self.h, _ptr(labels), B, T, _ptr(ll_out), _ptr(cnt_out),

@@ -358,15 +358,23 @@ class UnitLM(TokenLM):
     def log_likelihood(self, tokens: torch.Tensor, mean_nll: bool, ignore_tokens: Optional[List[int]] = None) -> torch.Tensor:
         """unit_lm.py:184-194 + calc_nll (calculation_utils.py:5-29): pad -> -100, per-sequence
         sum (or mean) of target log-probs."""
-        if ignore_tokens is not None:
-            raise NotImplementedError("ignore_tokens masking is an interleaved-tokeniser feature (out of scope)")
         B, T = tokens.shape
         ids = tokens.to(self.device, torch.int64).contiguous()
         lab = ids.clone()
         lab[lab == self.config.pad_token_id] = -100
         self._ensure_workspace(B * T)
         self._hold = (ids, lab)
-        self.engine.forward(ids, lab, None, None, None, B, T, 0.0, self._loss_buf, None)
+        mask = None
+        if ignore_tokens is not None:  # logits[:, :, ignore_tokens] = -inf (unit_lm.py:187-188), done inside the CE kernel
+            mask = torch.zeros(self.engine.padded_vocab(), dtype=torch.uint8, device=self.device)
+            mask[torch.as_tensor(list(ignore_tokens), dtype=torch.long, device=self.device)] = 1
+            self.engine.set_logit_mask(mask)
+        try:
+            self.engine.forward(ids, lab, None, None, None, B, T, 0.0, self._loss_buf, None)
+        finally:
+            if mask is not None:
+                torch.cuda.current_stream(self.device).synchronize()  # the kernel reads the mask: keep it alive until done
+                self.engine.set_logit_mask(None)
         ll = torch.empty(B, dtype=torch.float32, device=self.device)
         cnt = torch.empty(B, dtype=torch.float32, device=self.device)
         self.engine.seq_loglik(lab, B, T, ll, cnt)

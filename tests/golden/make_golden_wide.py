@@ -81,6 +81,11 @@ out["pack_logits"] = stitched.numpy().astype(np.float32)
 out["pack_loss_mean"] = np.float32(ref_compute_loss(stitched, flat["labels"]).item())
 m.eval()
 out["ll_mean"] = m.log_likelihood(ids.clone(), True).numpy().astype(np.float32)
+# modality-restricted scoring (unit_lm.py:187-188): logits of `ignore_tokens` are -inf before the softmax
+present = set(ids.flatten().tolist())
+ignore = [t for t in range(100, cfg.vocab) if t not in present][:250]
+out["ll_ignore_tokens"] = np.array(ignore, dtype=np.int64)
+out["ll_ignore_sum"] = m.log_likelihood(ids.clone(), False, ignore_tokens=ignore).numpy().astype(np.float32)
 
 out["meta_config"] = np.array(list(cfg.to_dict().items()), dtype=object).astype(str)
 out["meta_init"] = np.array([SEED, BIAS_STD, JIT], dtype=np.float64)

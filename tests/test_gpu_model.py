@@ -135,6 +135,34 @@ def test_log_likelihood_vs_reference_golden(tiny, golden_npz):
         ll = m.log_likelihood(ids, mean_nll).cpu().numpy()
         ref = golden_npz[key]
         assert np.allclose(ll, ref, rtol=5e-3, atol=2e-2), (key, ll, ref)
+    # ignore_tokens (one-wave CE kernel, V <= 512) against the oracle on the same bf16 weights
+    present = set(ids.flatten().tolist())
+    ignore = [t for t in range(50, cfg.vocab) if t not in present][:200]
+    got = m.log_likelihood(ids, False, ignore_tokens=ignore).cpu().numpy()
+    ref = O.log_likelihood(cfg, sd_bf, ids.clone(), False, ignore_tokens=ignore).numpy()
+    assert np.allclose(got, ref, rtol=5e-3, atol=0.3), (got, ref)
+    # a target inside the ignored set has zero probability: -inf log-likelihood, like the reference
+    bad = m.log_likelihood(ids, False, ignore_tokens=[int(ids[0, 3])]).cpu().numpy()
+    assert np.isneginf(bad[0])
+
+
+def test_backward_bucket_ranges_tile_the_flat_gradient(tiny, golden_npz):
+    """slam_bucket_cb ranges: disjoint, reported top-down, covering [0, n_params); the last (exposed) one only
+    holds layer 0 and the embedding."""
+    cfg, sd, sd_bf, m = tiny
+    ids, lab = (torch.from_numpy(golden_npz[k]) for k in ("pad_ids", "pad_labels"))
+    got = []
+    m.zero_grad()
+    m(input_ids=ids, labels=lab, return_logits=False)
+    m.backward(1.0, 1, lambda off, cnt: got.append((off, cnt)))
+    torch.cuda.synchronize()
+    n = m.engine.n_params
+    assert got[0][0] + got[0][1] == n and got[-1][0] == 0
+    for (o1, c1), (o2, c2) in zip(got, got[1:]):
+        assert o2 + c2 == o1 and c1 > 0 and c2 > 0
+    t = m.engine.tensors
+    assert got[-1][1] == t["layers.1.ln1"].offset  # embedding + layer 0
+
 
 
 def test_clip_and_adamw_step_vs_oracle(tiny, golden_npz):
@@ -258,6 +286,11 @@ def test_wide_config_vs_reference_golden_and_oracle(wide_golden):
         assert cosine(gv, gp_ref[k]) >= (0.99 if small else 0.999), k
     ll = m.log_likelihood(torch.from_numpy(g["pad_ids"]), True).cpu().numpy()
     assert np.allclose(ll, g["ll_mean"], rtol=5e-3, atol=2e-2)
+    # modality-restricted scoring: ignore_tokens are -inf inside the CE kernel (large-vocabulary kernel here)
+    lli = m.log_likelihood(torch.from_numpy(g["pad_ids"]), False, ignore_tokens=g["ll_ignore_tokens"].tolist()).cpu().numpy()
+    assert np.allclose(lli, g["ll_ignore_sum"], rtol=5e-3, atol=0.5), (lli, g["ll_ignore_sum"])
+    ll2 = m.log_likelihood(torch.from_numpy(g["pad_ids"]), True).cpu().numpy()
+    assert np.array_equal(ll, ll2)  # the mask is reset afterwards
     # determinism of the large-vocabulary path (token-ordered embedding scatter, no float atomics)
     g1 = m.flat_grads.clone()
     m.zero_grad()

@@ -173,3 +173,5 @@ def test_wide_config_matches_reference(wide_golden):
     assert abs(float(O.compute_loss(logits, lab)) - float(g["pack_loss_mean"])) <= 1e-6
     ll = O.log_likelihood(cfg, sd, torch.from_numpy(g["pad_ids"]).clone(), True)
     assert np.allclose(ll.numpy(), g["ll_mean"], rtol=1e-5, atol=1e-4)
+    lli = O.log_likelihood(cfg, sd, torch.from_numpy(g["pad_ids"]).clone(), False, ignore_tokens=g["ll_ignore_tokens"].tolist())
+    assert np.allclose(lli.numpy(), g["ll_ignore_sum"], rtol=1e-5, atol=1e-3)
