@@ -102,7 +102,10 @@ def dominant_kernel_roofline(model, iters=20):
     return {"bound": "mfma", "kernel": "gemm_kernel<NT, LDS-DMA ring 2, 4 waves, 128x128x64> gate|up + fused SwiGLU, M8192 N9728 K896",
             "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
-            "ms_per_launch": round(ms, 4), "traffic": None}
+            "ms_per_launch": round(ms, 4),
+            # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes): a recorded
+            # measurement of this same kernel and shape (profiles/r1_pmc_gateup_traffic.md), not collected live
+            "traffic": 677.8e6, "algorithmic_bytes": 271.2e6}
 
 
 def usable_cores() -> int:
