@@ -287,10 +287,15 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
 // ------------------------------------------------------------------------------------------
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
 // Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
-constexpr int DQ_NST = 2;
+// Ring depth of the two backward kernels: ONE stage. The operand set of a tile is large (dq: 3 images per 64
+// head-dim columns, dkv: 4 + the row scalars), so a second stage halves the blocks a CU can hold; the fetch of
+// a block is hidden by the MFMA phases of its co-resident blocks instead (head_dim 64: dq 24 KB -> 4 waves/SIMD,
+// dkv 33 KB -> 3; head_dim 128: dq 48 KB -> 3 blocks/CU, dkv 65 KB -> 2). Measured against the 2-stage ring:
+// backward 167 -> 155 us at head_dim 64 (8 x 1024 tokens, 14 heads), 464 -> 326 us at head_dim 128.
+template <int ND> struct BwdCfg { static constexpr int NST = 1; };
 template <int ND>
-__global__ __launch_bounds__(256, ND == 1 ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs p) {
-  constexpr int D = 64 * ND, STG = 3 * ND * IMG;
+__global__ __launch_bounds__(256, ND == 1 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, STG = 3 * ND * IMG, DQ_NST = BwdCfg<ND>::NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -351,10 +356,14 @@ __global__ __launch_bounds__(256, ND == 1 ? 3 : 1) void attn_bwd_dq_kernel(AttnA
   for (int fd = 0; fd < 4 * ND; ++fd) dq[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < n; ++t) {
+    if (DQ_NST == 1) {
+      __syncthreads();  // every wave is done with the single stage
+      issue(t);
+    }
     if (DQ_NST >= 3 && n - 1 - t >= 1) wait_vmcnt<6>();
     else wait_vmcnt<0>();
     __syncthreads();
-    if (t + DQ_NST - 1 < n) issue(t + DQ_NST - 1);
+    if (DQ_NST > 1 && t + DQ_NST - 1 < n) issue(t + DQ_NST - 1);
     const char* Ks = smem + (t % DQ_NST) * STG;
     const char* Kt = Ks + ND * IMG;
     const char* Vs = Ks + 2 * ND * IMG;
@@ -423,10 +432,9 @@ __global__ __launch_bounds__(256, ND == 1 ? 3 : 1) void attn_bwd_dq_kernel(AttnA
 // dkv_part[0|1][h][m][64] are summed over the heads of a KV group by attn_dkv_reduce_kernel.
 // Stage = Q D/T images + dO D/T images (32 KB) + lse2 / dsum / seg_start of the 64 query rows
 // (3 x 256 B, by 4-byte LDS-DMA), 2-stage ring, 9 DMAs per lane per tile.
-constexpr int DKV_NST = 2;
 template <int ND>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
-  constexpr int D = 64 * ND, DKV_STAGE = 4 * ND * IMG + 1024;
+__global__ __launch_bounds__(256, ND == 1 ? 3 : 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, DKV_STAGE = 4 * ND * IMG + 1024, DKV_NST = BwdCfg<ND>::NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                               : (const void*)(p.seg_start + row);
     glds4(src, __builtin_amdgcn_readfirstlane(st + 4 * ND * IMG + (uint32_t)wv * 256u));
   };
-  if (n > 0) issue(0);
+  if (DKV_NST > 1 && n > 0) issue(0);
 
   const int key = k0 + wave * 16 + l15;
   const int kc = key < M ? key : M - 1;
@@ -479,9 +487,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   for (int fd = 0; fd < 4 * ND; ++fd) { dk[fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[fd] = dk[fd]; }
 
   for (int t = 0; t < n; ++t) {
+    if (DKV_NST == 1) {
+      __syncthreads();
+      issue(t);
+    }
     wait_vmcnt<0>();
     __syncthreads();
-    if (t + 1 < n) issue(t + 1);
+    if (DKV_NST > 1 && t + 1 < n) issue(t + 1);
     const char* Qs = smem + (t % DKV_NST) * DKV_STAGE;
     const char* Qt = Qs + ND * IMG;
     const char* dOs = Qs + 2 * ND * IMG;
@@ -631,10 +643,10 @@ static int set_lds_attrs() {
                           FwdCfg<ND>::NST * FwdCfg<ND>::STAGE);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          DQ_NST * 3 * ND * IMG);
+                          BwdCfg<ND>::NST * 3 * ND * IMG);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<ND>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          DKV_NST * (4 * ND * IMG + 1024));
+                          BwdCfg<ND>::NST * (4 * ND * IMG + 1024));
   if (e != hipSuccess) return (int)e;
   done = true;
   return 0;
@@ -653,9 +665,9 @@ static int attn_bwd_nd(AttnArgs a, const int* plan, hipStream_t st) {
   const int M = a.M, nH = a.nH;
   const int nf = (M + 127) / 128, nq = (M + 63) / 64;
   a.perm = plan ? plan + nf : nullptr;
-  attn_bwd_dq_kernel<ND><<<nq * nH, 256, DQ_NST * 3 * ND * IMG, st>>>(a);
+  attn_bwd_dq_kernel<ND><<<nq * nH, 256, BwdCfg<ND>::NST * 3 * ND * IMG, st>>>(a);
   a.perm = plan ? plan + nf + nq : nullptr;
-  attn_bwd_dkv_kernel<ND><<<nq * nH, 256, DKV_NST * (4 * ND * IMG + 1024), st>>>(a);
+  attn_bwd_dkv_kernel<ND><<<nq * nH, 256, BwdCfg<ND>::NST * (4 * ND * IMG + 1024), st>>>(a);
   size_t total = (size_t)2 * M * a.nKV * (8 * ND);
   attn_dkv_reduce_kernel<ND><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
   return (int)hipGetLastError();
