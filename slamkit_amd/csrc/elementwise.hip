@@ -158,22 +158,36 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     dw_part[(size_t)blockIdx.x * H + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
 }
 
-// column sums of a bf16 matrix (bias gradient): part[block][N] fp32
+// column sums of a bf16 matrix (bias gradient): part[blockIdx.y][N] fp32. Block = 16 column chunks (8 columns
+// each) x 16 row lanes; a row lane walks rows lane, lane + 16 gridDim.y, ...; the 16 row lanes are combined in
+// LDS in a fixed order. Algorithmic traffic: 2 B/element read.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
                                                           float* __restrict__ part) {
-  // each thread owns 8 columns of one chunk, loops rows blockIdx.y, +gridDim.y ...
-  int c = blockIdx.x * 256 + threadIdx.x;  // chunk index
-  if (c * 8 >= N) return;
+  __shared__ float red[16][16 * 8 + 1];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;  // chunk index
+  const bool ok = c * 8 < N;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int m = blockIdx.y; m < M; m += gridDim.y) {
-    float f[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c * 8), f);
+  if (ok) {
+    for (int m = blockIdx.y * 16 + rl; m < M; m += gridDim.y * 16) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c * 8), f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] += f[j];
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
   }
-  float* o = part + (size_t)blockIdx.y * N + c * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = s[j];
+  for (int j = 0; j < 8; ++j) red[rl][cl * 8 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int col = blockIdx.x * 128 + threadIdx.x;
+    if (col < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+      part[(size_t)blockIdx.y * N + col] = t;
+    }
+  }
 }
 
 // out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 16 columns x 16 row-slices, fixed order.
@@ -781,12 +795,12 @@ int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, flo
   LAUNCH_RET();
 }
 
-int colsum_blocks(int M) { int b = (M + 31) / 32; return b > 256 ? 256 : (b < 1 ? 1 : b); }
+int colsum_blocks(int M) { int b = (M + 63) / 64; return b > 128 ? 128 : (b < 1 ? 1 : b); }
 
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st) {
   if (N & 7) return -1;
   int nb = colsum_blocks(M);
-  dim3 grid((N / 8 + 255) / 256, nb);
+  dim3 grid((N / 8 + 15) / 16, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
   if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0);
   LAUNCH_RET();

@@ -320,7 +320,7 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p, const f32x4_t (&acc)[4][4], int ro
 //             per flop - at ~1 PFLOP/s the 128x128 tile already pulls ~15 TB/s through the L2.
 template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4,
           int BMT = 128, int CMODE = 0 /* column-tile fragment assignment: 0 = 4-column, 1 = 8-column by DMA row order, 2 = 8-column by re-keyed swizzle */>
-__global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool GLDS = NSTAGE > 0;
   constexpr int THREADS = WAVES * 64;
@@ -463,13 +463,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_kernel(GemmArgs p) {
     for (int s = 0; s < D; ++s)
       if (s < nk) issue(s);
     for (int t = 0; t < nk; ++t) {
+      if constexpr (NSTAGE == 1) {
+        // single stage: no prefetch inside the block; three co-resident blocks per CU overlap each other
+        __syncthreads();
+        issue(t);
+      }
       // tile t has landed once at most min(D-1, nk-1-t) later tiles (8 DMAs each) are outstanding
       const int rem = min(D - 1, nk - 1 - t);
       if (D >= 3 && rem >= 2) wait_vmcnt<2 * PT>();
       else if (D >= 2 && rem == 1) wait_vmcnt<PT>();
       else wait_vmcnt<0>();
       __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
-      if (t + D < nk) issue(t + D);
+      if (NSTAGE > 1 && t + D < nk) issue(t + D);
       if constexpr (TR) compute_tr(t % NSTAGE);
       else compute(t % NSTAGE);
     }
@@ -1149,6 +1154,7 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   const int mode = dma_ok ? g_gemm_glds : 0;
   switch (mode) {
     case 2: return launch_nt2(a, st);
+    case 11: return launch<false, false, false, 1, 4, 128, 1>(a, 1, st);
     case 3: return launch<false, false, false, 3>(a, 1, st);
     case 4: return launch<false, false, false, 4>(a, 1, st);
     case 323: return launch_k32<3>(a, st);

@@ -12,7 +12,7 @@ def timeit(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 def rb(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
-modes = [int(a) for a in sys.argv[1:]] or [2, 323, 324, 325]
+modes = [int(a) for a in sys.argv[1:]] or [2, 11]
 cmodes = [int(c) for c in os.environ.get("CMODES", "1").split(",")]
 for name, (N, K) in {"qkv fwd": (1152, 896), "o fwd": (896, 896), "gate_up fwd": (9728, 896), "down fwd": (896, 4864),
                      "down dgrad": (4864, 896), "gate_up dgrad": (896, 9728)}.items():
