@@ -77,7 +77,7 @@ def w4_flops_per_batch(lens):
     return 6.0 * n_mm * sum(lens) + 3.0 * attn
 
 
-def dominant_kernel_roofline(model, iters=20):
+def dominant_kernel_roofline(model, iters=50, warm=40):
     """gate|up projection forward GEMM of one layer at the bench shape, timed with HIP events on the
     stream it is launched on (torch's current stream)."""
     from slamkit_amd import engine as E
@@ -88,7 +88,7 @@ def dominant_kernel_roofline(model, iters=20):
     y = torch.empty(M, N, dtype=torch.bfloat16, device=model.device)
     act = torch.empty(M, N // 2, dtype=torch.bfloat16, device=model.device)
     st = E.current_stream_ptr()
-    for _ in range(3):
+    for _ in range(warm):  # fresh 240 MB of outputs: the first few dozen launches run ~15 % slow (page / TLB warm-up)
         lib.slam_op_gemm_nt_swiglu(x.data_ptr(), w.data_ptr(), y.data_ptr(), act.data_ptr(), M, N, K, st)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
