@@ -123,6 +123,11 @@ int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t
 int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp_avg_sq, const float* norm_out,
                     double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
                     int32_t zero_grad, slam_stream_t stream);
+/* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
+ * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
+ * joins first. slam_join makes `stream` wait for a pending update before the caller touches the parameter, gradient or
+ * optimizer buffers itself (checkpointing, logging). */
+int slam_join(SlamEngine* h, slam_stream_t stream);
 int slam_zero_grads(SlamEngine* h, slam_stream_t stream);
 int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t stream); /* fp32 -> bound bf16 */
 

@@ -62,6 +62,21 @@ struct SlamEngine {
   bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
   int* embed_ws = nullptr;
   const uint8_t* logit_mask = nullptr;  // optional [vpad] bytes: non-zero = column excluded from the softmax
+
+  // optimizer overlap ("overlap_adamw"): AdamW + the weight-image refresh run in per-layer chunks on an
+  // engine-owned side stream; the next forward waits for chunk l right before layer l, so the HBM-bound update of
+  // the later layers runs under the MFMA-bound first layers of the next step
+  int overlap_adamw = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_chunk;  // [0] embedding, [1 + l] layer l, [L + 1] final norm
+  bool opt_pending = false;
+
+  ~SlamEngine() {
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
+  }
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -184,6 +199,31 @@ void add_tensor(SlamEngine* e, const std::string& name, int64_t& off, int64_t ro
     }                                                                                \
   } while (0)
 
+int ensure_side(SlamEngine* h) {
+  if (h->side) return 0;
+  hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if (e != hipSuccess) return (int)e;
+  h->ev_chunk.resize(h->d.n_layers + 2);
+  for (auto& ev : h->ev_chunk) {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+// make `st` wait for chunk i of a pending overlapped optimizer step
+int wait_chunk(SlamEngine* h, int i, hipStream_t st) {
+  if (!h->opt_pending) return 0;
+  return (int)hipStreamWaitEvent(st, h->ev_chunk[i], 0);
+}
+// ... for all of it (the chunks are recorded in order on one stream: the last event covers them)
+int join_optimizer(SlamEngine* h, hipStream_t st) {
+  if (!h->opt_pending) return 0;
+  h->opt_pending = false;
+  return (int)hipStreamWaitEvent(st, h->ev_chunk.back(), 0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -244,6 +284,7 @@ int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream) {
   if (!h->params_t) return SLAM_OK;
   if (!h->params) return h->fail(SLAM_ESTATE, "bind params first");
   hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
   const SlamModelDesc& d = h->d;
   const bf16_t* P = h->params;
   bf16_t* Pt = h->params_t;
@@ -297,6 +338,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_persist")) { gemm_set_persist((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_streamk")) { gemm_set_tn_streamk((int)value); return SLAM_OK; }
+  if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
@@ -328,10 +370,12 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
   }
   CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, h->attn_plan_buf, st));
   CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
+  CK(wait_chunk(h, 0, st));
   CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
   for (int l = 0; l < L; ++l) {
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
+    CK(wait_chunk(h, 1 + l, st));
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
     if (d.head_dim == 64 && (H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
       CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, nH + nKV, M, h->QKV, H, st));
@@ -350,6 +394,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     }
     CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
+  CK(join_optimizer(h, st));
   CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
   const int VP = h->vpad;
   CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
@@ -375,6 +420,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
   const SlamModelDesc& d = h->d;
   hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
   const int M = h->B * h->T;
   const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
   const int HD = nH * d.head_dim;
@@ -476,6 +522,7 @@ int slam_scale_loss_rows(SlamEngine* h, const float* seq_coef, int32_t B, int32_
 int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream) {
   if (!h || !norm_out) return SLAM_EINVAL;
   if (!h->grads || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");
+  CK(join_optimizer(h, (hipStream_t)stream));
   CK(grad_norm(h->grads, (size_t)h->n_params, max_norm, h->part_ws, norm_out, (hipStream_t)stream));
   return SLAM_OK;
 }
@@ -484,19 +531,57 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
                     double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
   if (!h || !master || !m || !v || step < 1) return SLAM_EINVAL;
   if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
-  CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad,
-           (hipStream_t)stream));
-  return slam_refresh_transposed(h, stream);
+  hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
+  if (!h->overlap_adamw) {
+    CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    return slam_refresh_transposed(h, stream);
+  }
+  CK(ensure_side(h));
+  CK((int)hipEventRecord(h->ev_fork, st));
+  CK((int)hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  const SlamModelDesc& d = h->d;
+  const int L = d.n_layers, H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
+  bf16_t* Pt = h->params_t;
+  for (int c = 0; c < L + 2; ++c) {
+    const int64_t lo = c == 0 ? 0 : c <= L ? h->lo[c - 1].ln1 : h->off_norm;
+    const int64_t hi = c == 0 ? h->lo[0].ln1 : c < L ? h->lo[c].ln1 : c == L ? h->off_norm : h->n_params;
+    CK(adamw(master + lo, h->params + lo, h->grads + lo, m + lo, v + lo, (size_t)(hi - lo), norm_out, lr, b1, b2, eps, wd, step,
+             zero_grad, h->side));
+    if (Pt) {
+      const bf16_t* P = h->params;
+      if (c == 0) {
+        CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, h->vpad, H, 1, 0, h->side));
+      } else if (c <= L) {
+        const LayerOff& o = h->lo[c - 1];
+        CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, 1, 0, h->side));
+        CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, 1, 0, h->side));
+        CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, 1, 0, h->side));
+        CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, 1, 0, h->side));
+      }
+    }
+    CK((int)hipEventRecord(h->ev_chunk[c], h->side));
+  }
+  h->opt_pending = true;
+  return SLAM_OK;
+}
+
+int slam_join(SlamEngine* h, slam_stream_t stream) {
+  if (!h) return SLAM_EINVAL;
+  CK(join_optimizer(h, (hipStream_t)stream));
+  return SLAM_OK;
 }
 
 int slam_zero_grads(SlamEngine* h, slam_stream_t stream) {
   if (!h || !h->grads) return SLAM_EINVAL;
+  CK(join_optimizer(h, (hipStream_t)stream));
   CK((int)hipMemsetAsync(h->grads, 0, (size_t)h->n_params * sizeof(float), (hipStream_t)stream));
   return SLAM_OK;
 }
 
 int slam_cast_params(SlamEngine* h, const float* master, slam_stream_t stream) {
   if (!h || !master || !h->params) return SLAM_EINVAL;
+  CK(join_optimizer(h, (hipStream_t)stream));
   CK(f32_to_bf16(master, h->params, (size_t)h->n_params, (hipStream_t)stream));
   return slam_refresh_transposed(h, stream);
 }

@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None):
         "slam_scale_loss_rows": (C.c_int, [vp, vp, i32, i32, vp]),
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
         "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
         "slam_set_option": (C.c_int, [vp, C.c_char_p, i64]),
@@ -231,6 +232,10 @@ class Engine:
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))
+
+    def join(self, stream=None):
+        """Order `stream` after a pending overlapped optimizer step (call before reading the flat buffers with torch)."""
+        self._ck(self.lib.slam_join(self.h, stream if stream is not None else current_stream_ptr()))
 
     def cast_params(self, master, stream=None):
         self._ck(self.lib.slam_cast_params(self.h, _ptr(master),

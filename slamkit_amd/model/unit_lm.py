@@ -232,6 +232,7 @@ class UnitLM(TokenLM):
         norms, zero padding_idx row (unit_lm.py:114-115 -> transformers PreTrainedModel)."""
         std = float(self.config.base_config["initializer_range"])
         g = torch.Generator(device=self.device).manual_seed(seed)
+        self.engine.join()
         self.flat_master.zero_()
         for k in self.key_map:
             v = self._view(self.flat_master, k, writable=True)
@@ -249,6 +250,7 @@ class UnitLM(TokenLM):
         self.engine.cast_params(self.flat_master)
 
     def named_parameters(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        self.engine.join()  # a pending overlapped optimizer step writes these buffers on the engine's side stream
         for k in self.key_map:
             yield k, self._view(self.flat_params, k)
 
@@ -257,6 +259,7 @@ class UnitLM(TokenLM):
             yield v
 
     def named_grads(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        self.engine.join()
         for k in self.key_map:
             yield k, self._view(self.flat_grads, k)
 
@@ -264,11 +267,13 @@ class UnitLM(TokenLM):
         return sum(v.numel() for v in self.parameters())
 
     def state_dict(self, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+        self.engine.join()
         src = self.flat_master if dtype == torch.float32 else self.flat_params
         return {k: self._view(src, k).detach().to(dtype).cpu().clone() for k in self.key_map}
 
     @torch.no_grad()
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        self.engine.join()
         missing = [k for k in self.key_map if k not in sd]
         extra = [k for k in sd if k not in self.key_map and not k.endswith("lm_head.weight")]
         if strict and (missing or extra):

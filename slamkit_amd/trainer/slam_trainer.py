@@ -54,6 +54,9 @@ class SLAMTrainer:
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
         self.opt_step = 0
+        # engine option: AdamW + weight-image refresh in per-layer chunks on the engine's side stream; slam_forward
+        # waits per layer. Everything that reads the flat buffers with torch goes through UnitLM (which joins first).
+        model.engine.set_option("overlap_adamw", 1 if getattr(args, "overlap_optimizer", False) else 0)
 
     # ---- reference hooks ------------------------------------------------------------------------
     def get_num_tokens(self, labels: torch.Tensor) -> int:
@@ -209,6 +212,7 @@ class SLAMTrainer:
         for cb in self.callbacks:
             cb.on_train_end(a, self.state, self.control)
         torch.cuda.synchronize(self.model.device)
+        self.model.engine.join()  # a pending overlapped optimizer step: order it before whatever the caller does next
         return self.state
 
     @torch.no_grad()
@@ -255,6 +259,7 @@ class SLAMTrainer:
         if self.rank == 0:
             path = self._ckpt_dir(self.state.global_step)
             self.model.save_pretrained(path)
+            self.model.engine.join()
             torch.save({"master": self.model.flat_master.cpu(), "exp_avg": self.exp_avg.cpu(),
                         "exp_avg_sq": self.exp_avg_sq.cpu(), "opt_step": self.opt_step}, os.path.join(path, "optimizer.pt"))
             with open(os.path.join(path, "trainer_state.json"), "w") as f:
@@ -274,6 +279,7 @@ class SLAMTrainer:
 
     def _load_checkpoint(self, path: str):
         st = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+        self.model.engine.join()
         self.model.flat_master.copy_(st["master"])
         self.model.sync_params_from_master()
         self.exp_avg.copy_(st["exp_avg"])

@@ -164,6 +164,31 @@ def test_loss_curve_60_steps_vs_oracle():
         assert abs(a - b) <= 0.01 * b + 1e-2, (a, b)
 
 
+def test_overlapped_optimizer_is_bit_identical():
+    """overlap_optimizer=True (AdamW in per-layer chunks on the engine's side stream, forward waits per layer) must give
+    exactly the parameters of the in-order step."""
+    from slamkit_amd.data import DataCollatorForLanguageModeling, TokenDataset
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    cfg = O.TINY
+    sd = O.init_weights(cfg, seed=2, bias_std=0.02, norm_jitter=0.05)
+    g = torch.Generator().manual_seed(1)
+    rows = [{"input_ids": [1] + torch.randint(2, 502, (40,), generator=g).tolist() + [1], "attention_mask": [1] * 42} for _ in range(32)]
+    outs = []
+    for overlap in (False, True):
+        m = _tiny_model(sd)
+        args = SLAMTrainingArguments(per_device_train_batch_size=4, gradient_accumulation_steps=1, num_train_epochs=1,
+                                     warmup_steps=2, warmup_ratio=0.0, learning_rate=2e-3, logging_steps=1, max_grad_norm=0.5,
+                                     weight_decay=0.01, seed=3, output_dir="/tmp/unused", overlap_optimizer=overlap)
+        tr = SLAMTrainer(model=m, args=args, data_collator=DataCollatorForLanguageModeling(pad_token_id=0),
+                         train_dataset=TokenDataset(rows))
+        st = tr.train()
+        outs.append((m.state_dict(torch.float32), [r["loss"] for r in st.log_history if "loss" in r], tr.exp_avg.clone()))
+    assert outs[0][1] == outs[1][1]
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_checkpoint_roundtrip_and_resume(tmp_path):
     from slamkit_amd.data import DataCollatorForLanguageModeling, TokenDataset
     from slamkit_amd.model import UnitLM
