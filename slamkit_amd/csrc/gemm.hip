@@ -761,6 +761,112 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs p) {
   wait_vmcnt<0>();  // the trailing dummy fetch must not land in a successor block's LDS
 }
 
+// ---- 128 x 112 tiles for the N = 896 projections --------------------------------------------------------
+// M 8192 x N 896 gives 448 tiles of 128 x 128 for the 512 block slots (2 per CU): a quarter of the CUs run one
+// block instead of two and the launch takes as long as a full one. 896 = 8 x 112: with 128 x 112 tiles there are
+// exactly 512. 112 columns are 7 MFMA fragments, so the four waves split the ROWS (32 each, 2 x 7 fragments per
+// wave) and every wave reads the whole column tile: 9 fragment reads per 14 MFMAs instead of 8 per 16.
+// Same LDS layout, swizzle, DMA ring and swapped MFMA roles as gemm_kernel; 4-column epilogue (bias, residual).
+__global__ __launch_bounds__(256, 2) void gemm_nt_n112_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN2 = 112;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * BM, col0 = tc_ * BN2;
+  const int nk = p.Kc / BK;
+  f32x4_t acc[2][7];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const uint32_t lds0 = lds_addr(smem);
+  uint32_t voa[4], vob[4];
+  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // column tile: rows 112..127 of the LDS image repeat row 111 (never read)
+    const int P = i * 256 + tid, row = P >> 3, c = (P & 7) ^ lds_swz_key(row);
+    const int gr = col0 + (row < BN2 ? row : BN2 - 1);
+    vob[i] = (uint32_t)(((size_t)gr * p.ldb + c * 8) * sizeof(bf16_t));
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t & 1) * STAGE_BYTES);
+    glds_tile<256, 128>(p.A + t * BK, voa, wv, st);
+    glds_tile<256, 128>(p.B + t * BK, vob, wv, st + TILE_BYTES);
+  };
+  const int ka = (l15 >> 1) & 7;  // swizzle key of row f*16 + l15 is (ka ^ f) & 7
+  if (nk > 0) issue(0);
+  for (int t = 0; t < nk; ++t) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (t + 1 < nk) issue(t + 1);
+    const char* At = smem + (t & 1) * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[7], bf[2];
+#pragma unroll
+      for (int f = 0; f < 7; ++f)
+        af[f] = *reinterpret_cast<const uint4*>(Bt + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        bf[f] = *reinterpret_cast<const uint4*>(At + (wave * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (2 * wave + f)) & 7) << 4));
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 7; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
+    }
+  }
+  uint2 bb[7];
+  if (p.bias) {
+#pragma unroll
+    for (int fn = 0; fn < 7; ++fn) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + fn * 16 + g * 4);
+  }
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+    const int m = row0 + wave * 32 + fm * 16 + l15;
+    const bool mok = m < p.R;
+    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+    uint2 rr[7];
+    if (p.resid) {
+#pragma unroll
+      for (int fn = 0; fn < 7; ++fn) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + fn * 16 + g * 4);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 7; ++fn) {
+      f32x4_t v = acc[fm][fn];
+      if (p.bias) {
+        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
+      }
+      if (p.resid) {
+        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + fn * 16 + g * 4) = o;
+    }
+  }
+}
+
 // ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
 //      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
 //      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
@@ -1107,6 +1213,29 @@ static int g_gemm_glds = 2;
 static int g_gemm_cmode = 1;
 void gemm_set_cmode(int m) { g_gemm_cmode = m; }
 // the default NT kernel (2-stage ring, 4 waves) in the selected column-tile layout
+static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)
+void gemm_set_n112(int on) { g_gemm_n112 = on; }
+// 128 x 112 tiles when they fill the 512 block slots better than 128 x 128 ones (N = 896: 512 vs 448 tiles)
+static bool use_n112(const GemmArgs& a) {
+  if (!g_gemm_n112 || a.Cn % 112 || a.act || a.gu || a.rope_cos) return false;
+  const int tr = (a.R + BM - 1) / BM;
+  auto fill = [](int tiles) { return (double)tiles / (double)(((tiles + 511) / 512) * 512); };
+  return fill(tr * (a.Cn / 112)) > fill(tr * (a.Cn / BN)) + 0.05;
+}
+static int launch_n112(GemmArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_n112_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.tiles_r = (a.R + BM - 1) / BM;
+  a.tiles_c = a.Cn / 112;
+  a.group_rows = g_group_rows;
+  gemm_nt_n112_kernel<<<a.tiles_r * a.tiles_c, 256, 2 * STAGE_BYTES, st>>>(a);
+  return (int)hipGetLastError();
+}
 static int g_gemm_persist = 0;  // measured neutral at kernel and step level (30.26 vs 30.20 ms): kept selectable ("gemm_persist")
 void gemm_set_persist(int on) { g_gemm_persist = on; }
 static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
@@ -1125,6 +1254,7 @@ static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
     gemm_nt_persist_kernel<<<512, 256, 2 * STAGE_BYTES, st>>>(a);
     return (int)hipGetLastError();
   }
+  if (use_n112(a0)) return launch_n112(a0, st);
   const GemmArgs& a = a0;
   switch (g_gemm_cmode) {
     case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);

@@ -48,6 +48,23 @@ def test_gemm_nt_persistent_variant(M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_gemm_nt_n112_variant():
+    """The selectable 128 x 112 tiling (N = 896 -> exactly 512 tiles at M = 8192) gives the same bits as the default."""
+    M, N, K = 1100, 896, 256
+    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
+    outs = []
+    for on in (0, 1):
+        assert lib().slam_set_option(None, b"gemm_n112", on) == 0
+        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
+        sync()
+        outs.append(Y)
+    lib().slam_set_option(None, b"gemm_n112", 0)
+    check("gemm_nt n112", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 192, 384), (300, 512, 256), (1000, 1152, 896),
                                    (74, 1024, 256)])
 def test_gemm_nn(M, N, K):
