@@ -100,7 +100,7 @@ SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
 
 // ------------------------------------------------------------------------------------------
 // Forward. grid (ceil(M/128), nH); wave w owns query rows q0+32w .. +31 (two 16-row fragments).
-// Stage = K D-image + V T-image (16 KB), 3-stage ring, 4 DMAs per lane per tile.
+// Stage = K D-image + V T-image (16 KB per 64 head-dim columns), 3-stage ring at head_dim 64 / 2-stage at 128.
 template <int ND>
 struct FwdCfg {
   static constexpr int NST = ND == 1 ? 3 : 2;   // ring depth: 48 KB (3 blocks/CU) or 64 KB (2 blocks/CU)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
 
 // ------------------------------------------------------------------------------------------
 // dQ. grid (ceil(M/64), nH); wave w owns query rows q0+16w .. +15.
-// Stage = K D-image + K T-image + V D-image (24 KB), 3-stage ring, 6 DMAs per lane per tile.
+// Stage = K D-image + K T-image + V D-image (24 KB per 64 head-dim columns), 6 DMAs per lane per tile and sub-image.
 // Ring depth of the two backward kernels: ONE stage. The operand set of a tile is large (dq: 3 images per 64
 // head-dim columns, dkv: 4 + the row scalars), so a second stage halves the blocks a CU can hold; the fetch of
 // a block is hidden by the MFMA phases of its co-resident blocks instead (head_dim 64: dq 24 KB -> 4 waves/SIMD,

@@ -18,7 +18,13 @@
 //   * register staging, direct or with an 8x8 in-register transpose (branch-free loads so the
 //     next tile's loads stay in flight across the MFMA block).
 // MFMA roles are swapped (a-operand = column tile, b-operand = row tile) so a lane ends up holding
-// four consecutive output columns of one row -> 8-byte bf16 / 16-byte fp32 stores.
+// consecutive output columns of one row: four per fragment, and eight (16-byte accesses) in the
+// default NT layout, where the column tile's rows are DMA'd in the perm64 order.
+//
+// Kernels in this file: gemm_kernel (NT / NN / register-staged TN, every fused epilogue; the default),
+// gemm_tn_bal_kernel + reduce_bal_kernel (wgrad, balanced K-splitting), and the measured-but-not-default
+// variants kept selectable through slam_set_option for A/B runs: gemm_nt_persist_kernel,
+// gemm_nt_n112_kernel, gemm_nt_k32_kernel (DESIGN.md §4 lists what each one showed).
 #include "common.h"
 #include "kernels.h"
 
