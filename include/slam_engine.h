@@ -132,7 +132,10 @@ int slam_zero_grads(SlamEngine* h, slam_stream_t stream);
 int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t stream); /* fp32 -> bound bf16 */
 
 /* ---- tuning knobs ---------------------------------------------------------------------------*/
-int slam_set_option(SlamEngine* h, const char* key, int64_t value); /* "gemm_glds" = 0|1 */
+/* Tuning / mode switches. "grad_overwrite_next" = 1: the next slam_backward stores the gradients instead of adding to
+ * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "overlap_adamw",
+ * "fuse_swiglu", "fuse_dswiglu" and the "gemm_*" keys select measured kernel variants. */
+int slam_set_option(SlamEngine* h, const char* key, int64_t value);
 
 /* ---- single-op entry points (parity tests call each kernel through the ABI) -------------------*/
 int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,

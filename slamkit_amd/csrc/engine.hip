@@ -66,6 +66,7 @@ struct SlamEngine {
   // optimizer overlap ("overlap_adamw"): AdamW + the weight-image refresh run in per-layer chunks on an
   // engine-owned side stream; the next forward waits for chunk l right before layer l, so the HBM-bound update of
   // the later layers runs under the MFMA-bound first layers of the next step
+  bool overwrite_next = false;  // "grad_overwrite_next": the next backward stores gradients instead of adding to them
   int overlap_adamw = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr;
@@ -340,6 +341,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_n112")) { gemm_set_n112((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_streamk")) { gemm_set_tn_streamk((int)value); return SLAM_OK; }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
@@ -436,11 +438,16 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   const int VP = h->vpad;
   if (grad_scale != 1.0f) CK(scale_bf16(h->dlogits, (size_t)M * VP, grad_scale, st));
   // tied head: dE += dlogits^T hf ; dhf = dlogits E
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, st));
+  // first micro-batch of an optimizer step: every gradient tensor is written exactly once below (the embedding
+  // twice: head first, gather side second), so it may be STORED instead of accumulated and the buffer needs no
+  // zeroing pass (4 B/param written by AdamW + 4 B/param re-read by the wgrad epilogues)
+  const int acc = h->overwrite_next ? 0 : 1;
+  h->overwrite_next = false;
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, st));
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
-  CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, 1, h->part_ws, M, H, st));
+  CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
   int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
@@ -449,23 +456,23 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
     // MLP
-    CK(gemm_tn(dh, a.act, G + o.wd, 1, M, H, I, H, I, h->gemm_ws, st));
+    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, st));
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
     } else {
       CK(dgrad(dh, o.wd, h->dact, H, I));
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
-    CK(gemm_tn(a.gu, a.x2, G + o.wgu, 1, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
+    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(gemm_tn(dh2, a.o, G + o.wo, 1, M, H, HD, H, HD, h->gemm_ws, st));
+    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, st));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->cosb, h->sinb, M,
                 nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, 1, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
+    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
     // bucket boundaries: every `bl` layers from the top, and after each of the last two layers so that the
@@ -475,9 +482,9 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
       const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, 1, st));
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, 1, st));
-      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, 1, st));
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st));
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st));
+      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st));
       fin_hi = l;
     }
     if (boundary) {

@@ -135,6 +135,8 @@ class SLAMTrainer:
         else:
             n_items, scale = local_items, 1.0 / self.world  # per-rank token mean, then rank average
         for i, mb in enumerate(micro):
+            if i == 0 and a.overwrite_first_grad:  # the first backward of the step stores the gradients: no zeroing pass
+                self.model.engine.set_option("grad_overwrite_next", 1)
             loss = self.training_step(self.model, mb, num_items_in_batch=n_items, last_micro=(i == len(micro) - 1),
                                       grad_scale=scale)
             self._loss_acc += loss if a.average_tokens_across_devices else loss / len(micro)
@@ -145,7 +147,7 @@ class SLAMTrainer:
         eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
         self.opt_step += 1
         eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
-                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=True)
+                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=not a.overwrite_first_grad)
         self.state.global_step += 1
 
     def _log(self, lr: float, t0: float, tokens0: int):
