@@ -10,7 +10,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(dst, "w") as f:
     f.write(f"# {title}\n\n")
     f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline` "
-            f"on 1x MI355X ({steps} optimizer steps of Slam-358M B=8 T=1024, plus the roofline probe's 23 gate|up GEMM launches "
+            f"on 1x MI355X ({steps} optimizer steps of Slam-358M B=8 T=1024, plus the roofline probe's 90 gate|up GEMM launches (~16 ms of the NT GEMM total) "
             "and model init).\n\n")
     f.write(f"Total kernel time {tot/1e6:.1f} ms -> {tot/1e6/steps:.1f} ms of kernels per optimizer step.\n\n")
     f.write("| kernel | calls | total ms | avg us | % | ms/step |\n|---|---|---|---|---|---|\n")
