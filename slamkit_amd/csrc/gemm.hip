@@ -25,6 +25,8 @@
 // gemm_tn_bal_kernel + reduce_bal_kernel (wgrad, balanced K-splitting), and the measured-but-not-default
 // variants kept selectable through slam_set_option for A/B runs: gemm_nt_persist_kernel,
 // gemm_nt_n112_kernel, gemm_nt_k32_kernel (DESIGN.md §4 lists what each one showed).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -873,6 +875,166 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_n112_kernel(GemmArgs p) {
   }
 }
 
+// ---- 256 x 256 tiles, 8 waves, 8-phase schedule ------------------------------------------------------------
+// For the wide-N projections (gate|up forward, down-proj dgrad). Eight waves as 2 (rows) x 4 (columns), each
+// owning 128 x 64 of the output (acc = 128 VGPRs); one block per CU (128 KB of LDS: two K-tile buffers of four
+// 16 KB half-tiles). A K-tile is consumed in four phases, one 64 x 32 quadrant of the wave's output each
+// (16 MFMAs): the half-tiles are cut so that a phase needs at most one new one -
+//   Amq_h = rows {64h .. 64h+63} of BOTH wave rows,  Bnq_h = columns {32h .. 32h+31} of ALL FOUR wave columns,
+//   phase 1: Amq0 + Bnq0 -> quadrant (0,0); 2: Bnq1 -> (0,1); 3: Amq1 -> (1,1); 4: Bnq0 again (registers) -> (1,0)
+// and every phase issues the DMA of ONE half-tile of the next K-tile (same order), so three half-tiles are
+// always in flight and the counted vmcnt never drains. Each phase is
+//   [issue DMA | ds_read the new fragments | counted vmcnt] barrier [16 MFMA at raised priority] barrier
+// and the second wave row runs one barrier behind the first: while one wave of a SIMD is in its MFMA section the
+// other one is loading, by construction rather than by chance. A wait that retires a half-tile sits in the
+// phase BEFORE the one that reads it (the barrier in between publishes every wave's DMA).
+// Column-tile rows are in the perm64 order, so the epilogue is epilogue8 on the two 64-row halves.
+template <bool LAST>
+SLAM_DEVICE void wait_ph(int which) {
+  // outstanding half-tiles (2 DMAs each) allowed after the wait: 2 in steady state, fewer on the last K-tile
+  if (which == 0) { if (LAST) wait_vmcnt<2>(); else wait_vmcnt<4>(); }
+  else if (which == 1) { if (LAST) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
+  else { if (!LAST) wait_vmcnt<4>(); }
+}
+SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
+  constexpr int KT = 4 * HT;         // K-tile buffer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * 256, col0 = tc_ * 256;
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  // DMA source offsets, 2 chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
+  uint32_t vo[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int P = i * 512 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int grow = row0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      const int gcol = col0 + (r >> 5) * 64 + perm64(h * 32 + (r & 31));
+      vo[h ? 3 : 0][i] = (uint32_t)(((size_t)grow * p.lda + c * 8) * sizeof(bf16_t));
+      vo[1 + h][i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
+    }
+  }
+  auto issue_half = [&](int h, int t) {  // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1)
+    const bf16_t* base = ((h == 0 || h == 3) ? p.A : p.B) + (size_t)t * BK;
+    const uint32_t dst = lds0 + (uint32_t)((t & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
+  };
+
+  f32x4_t acc[2][4][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a half-tile
+  const int ka = (l15 >> 1) & 7;
+  int offA[4], offB[2];  // byte offsets of row (wave block + f*16 + l15), without the chunk term
+#pragma unroll
+  for (int f = 0; f < 4; ++f) offA[f] = (wr * 64 + f * 16 + l15) * 128;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) offB[f] = (wc * 32 + f * 16 + l15) * 128;
+  uint4 afr[2][4], bfr[2][2][2];  // [kk][fm], [nq][kk][fn]
+  auto read_A = [&](const char* half) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        afr[kk][f] = *reinterpret_cast<const uint4*>(half + offA[f] + ((((g + 4 * kk) ^ ka ^ (wr * 4 + f)) & 7) << 4));
+  };
+  auto read_B = [&](const char* half, int nq) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(half + offB[f] + ((((g + 4 * kk) ^ ka ^ (wc * 2 + f)) & 7) << 4));
+  };
+  auto mma = [&](int mq, int nq) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn)
+          acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](int t, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const char* buf = smem + (t & 1) * KT;
+    // phase 1
+    if (!LAST) issue_half(0, t + 1);
+    read_A(buf);
+    read_B(buf + HT, 0);
+    wait_ph<LAST>(0);  // Bnq1(t) landed -> read in phase 2
+    raw_barrier();
+    mma(0, 0);
+    raw_barrier();
+    // phase 2
+    if (!LAST) issue_half(1, t + 1);
+    read_B(buf + 2 * HT, 1);
+    wait_ph<LAST>(1);  // Amq1(t) landed -> read in phase 3
+    raw_barrier();
+    mma(0, 1);
+    raw_barrier();
+    // phase 3
+    if (!LAST) issue_half(2, t + 1);
+    read_A(buf + 3 * HT);
+    raw_barrier();
+    mma(1, 1);
+    raw_barrier();
+    // phase 4
+    if (!LAST) issue_half(3, t + 1);
+    wait_ph<LAST>(2);  // Amq0(t+1), Bnq0(t+1) landed -> read in phase 1 of the next K-tile
+    raw_barrier();
+    mma(1, 0);
+    raw_barrier();
+  };
+
+  // prologue: K-tile 0 in the order it is needed; phase 1 needs the first two half-tiles
+  issue_half(0, 0);
+  issue_half(1, 0);
+  issue_half(2, 0);
+  issue_half(3, 0);
+  wait_vmcnt<4>();
+  raw_barrier();
+  if (wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
+  for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
+  ktile(nk - 1, std::true_type{});
+  if (wr == 0) raw_barrier();  // balance the barrier count
+
+  epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
+  epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
+}
+
 // ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
 //      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
 //      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
@@ -1219,6 +1381,31 @@ static int g_gemm_glds = 2;
 static int g_gemm_cmode = 1;
 void gemm_set_cmode(int m) { g_gemm_cmode = m; }
 // the default NT kernel (2-stage ring, 4 waves) in the selected column-tile layout
+static int g_gemm_256 = 1;
+void gemm_set_256(int on) { g_gemm_256 = on; }
+// the 256 x 256 kernel runs one block per CU: worth it when the tiles fill whole rounds of the 256 CUs
+// (gate|up forward: 1216 tiles = 4.75 rounds, 95 %; down-proj dgrad: 608 tiles = 2.4 rounds, 79 % -> 128 x 128)
+static bool use_256(const GemmArgs& a) {
+  if (!g_gemm_256 || (a.R % 256) || (a.Cn % 256) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
+  const int tiles = (a.R / 256) * (a.Cn / 256);
+  if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
+  return tiles >= 512 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.9;
+}
+static int launch_256(GemmArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.tiles_r = a.R / 256;
+  a.tiles_c = a.Cn / 256;
+  a.group_rows = g_group_rows > 1 ? (g_group_rows + 1) / 2 : 1;
+  a.nt_store = g_nt_store;
+  gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  return (int)hipGetLastError();
+}
 static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)
 void gemm_set_n112(int on) { g_gemm_n112 = on; }
 // 128 x 112 tiles when they fill the 512 block slots better than 128 x 128 ones (N = 896: 512 vs 448 tiles)
@@ -1261,6 +1448,7 @@ static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
   }
   if (use_n112(a0)) return launch_n112(a0, st);
+  if (g_gemm_cmode == 1 && use_256(a0)) return launch_256(a0, st);
   const GemmArgs& a = a0;
   switch (g_gemm_cmode) {
     case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);

@@ -17,6 +17,7 @@ void gemm_set_cmode(int m);
 void gemm_set_nt_store(int on);
 void gemm_set_persist(int on);
 void gemm_set_n112(int on);
+void gemm_set_256(int on);
 void gemm_set_tn_streamk(int on);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);

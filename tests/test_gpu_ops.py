@@ -48,6 +48,34 @@ def test_gemm_nt_persistent_variant(M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 128), (2048, 8192, 192), (4096, 2048, 64 * 5)])
+def test_gemm_nt_256_tile_kernel(M, N, K):
+    """The 256 x 256 / 8-wave / 8-phase kernel (default for the gate|up forward) against the 128 x 128 kernel: same
+    bits for plain, bias + residual and fused-SwiGLU epilogues, and both against the fp32 reference."""
+    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
+    outs = {}
+    for mode in (0, 2):  # 0 = 128 x 128 only, 2 = 256 x 256 whenever the shape allows
+        assert lib().slam_set_option(None, b"gemm_256", mode) == 0
+        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
+        Yp = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Yp), None, None, M, N, K, 2, stream()) == 0
+        Ys = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        act = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib().slam_op_gemm_nt_swiglu(ptr(Xd), ptr(Wd), ptr(Ys), ptr(act), M, N, K, stream()) == 0
+        sync()
+        outs[mode] = (Y, Yp, Ys, act)
+    lib().slam_set_option(None, b"gemm_256", 1)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)
+    ref = X @ W.t()
+    check("gemm 256 bias+resid", outs[2][0].float(), ref + bias + res, 4e-3, 2e-2)
+    check("gemm 256 plain", outs[2][1].float(), ref, 4e-3, 2e-2)
+    gu = ref.view(M, N // 64, 2, 32)
+    check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
+
+
 def test_gemm_nt_n112_variant():
     """The selectable 128 x 112 tiling (N = 896 -> exactly 512 tiles at M = 8192) gives the same bits as the default."""
     M, N, K = 1100, 896, 256

@@ -14,18 +14,25 @@ def timeit(fn, iters=20):
 def rb(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 modes = [int(a) for a in sys.argv[1:]] or [2, 11]
 cmodes = [int(c) for c in os.environ.get("CMODES", "1").split(",")]
-n112s = [int(c) for c in os.environ.get("N112", "1").split(",")]
+n112s = [int(c) for c in os.environ.get("N112", "0").split(",")]
+g256s = [int(c) for c in os.environ.get("G256", "0").split(",")]
+ref = {}
+def run(name, N, K, mode, cm, n112, g256):
+    x, w = data[name]
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, mode, st))
+    if name not in ref: ref[name] = y
+    ok = torch.equal(ref[name], y)
+    print(f"nt {name:16s} mode {mode:4d} cmode {cm} n112 {n112} g256 {g256} {us:8.1f} us {2.0*M*N*K/us/1e6:8.1f} TF  same={ok}", flush=True)
+data = {}
 for name, (N, K) in {"qkv fwd": (1152, 896), "o fwd": (896, 896), "gate_up fwd": (9728, 896), "down fwd": (896, 4864),
                      "down dgrad": (4864, 896), "gate_up dgrad": (896, 9728)}.items():
-    x, w = rb(M, K), rb(N, K)
-    ref = None
+    data[name] = (rb(M, K), rb(N, K))
     for mode in modes:
       for cm in (cmodes if mode == 2 else [0]):
        for n112 in (n112s if mode == 2 else [0]):
-        lib.slam_set_option(None, b"gemm_cmode", cm)
-        lib.slam_set_option(None, b"gemm_n112", n112)
-        y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
-        us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, mode, st))
-        if ref is None: ref = y
-        ok = torch.equal(ref, y)
-        print(f"nt {name:16s} mode {mode:4d} cmode {cm} n112 {n112} {us:8.1f} us {2.0*M*N*K/us/1e6:8.1f} TF  same={ok}", flush=True)
+        for g256 in (g256s if mode == 2 else [0]):
+         lib.slam_set_option(None, b"gemm_cmode", cm)
+         lib.slam_set_option(None, b"gemm_n112", n112)
+         lib.slam_set_option(None, b"gemm_256", g256)
+         run(name, N, K, mode, cm, n112, g256)

@@ -15,7 +15,7 @@ def timeit(fn, iters=20):
 for rep in range(2):
   for stg in (0, 1, 0, 1):
     nt = stg
-    lib.slam_set_option(None, b"gemm_persist", stg)
+    lib.slam_set_option(None, b"gemm_256", stg)
     f = timeit(lambda: lib.slam_op_gemm_nt_swiglu(x.data_ptr(), w.data_ptr(), y.data_ptr(), a.data_ptr(), M, N, K, st))
     p = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 2, st))
-    print(f"persist={nt}: fused {f:7.1f} us  plain {p:7.1f} us")
+    print(f"g256={nt}: fused {f:7.1f} us  plain {p:7.1f} us")
