@@ -898,6 +898,7 @@ SLAM_DEVICE void wait_ph(int which) {
 }
 SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+template <int VAR>  // 0 = as described; measured against it: 1 = one barrier per phase, no stagger (+3 % time), 2 = no priority raise (+8 %)
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
@@ -925,7 +926,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   const int nk = p.Kc / BK;
   const uint32_t lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-
   // DMA source offsets, 2 chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
   uint32_t vo[4][2];
 #pragma unroll
@@ -976,8 +976,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
       for (int f = 0; f < 2; ++f)
         bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(half + offB[f] + ((((g + 4 * kk) ^ ka ^ (wc * 2 + f)) & 7) << 4));
   };
+  auto barrier_b = [&]() { if (VAR != 1) raw_barrier(); };
   auto mma = [&](int mq, int nq) {
-    __builtin_amdgcn_s_setprio(1);
+    if (VAR != 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
         for (int fn = 0; fn < 2; ++fn)
           acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
-    __builtin_amdgcn_s_setprio(0);
+    if (VAR != 2) __builtin_amdgcn_s_setprio(0);
   };
   auto ktile = [&](int t, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
@@ -997,26 +998,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     wait_ph<LAST>(0);  // Bnq1(t) landed -> read in phase 2
     raw_barrier();
     mma(0, 0);
-    raw_barrier();
+    barrier_b();
     // phase 2
     if (!LAST) issue_half(1, t + 1);
     read_B(buf + 2 * HT, 1);
     wait_ph<LAST>(1);  // Amq1(t) landed -> read in phase 3
     raw_barrier();
     mma(0, 1);
-    raw_barrier();
+    barrier_b();
     // phase 3
     if (!LAST) issue_half(2, t + 1);
     read_A(buf + 3 * HT);
     raw_barrier();
     mma(1, 1);
-    raw_barrier();
+    barrier_b();
     // phase 4
     if (!LAST) issue_half(3, t + 1);
     wait_ph<LAST>(2);  // Amq0(t+1), Bnq0(t+1) landed -> read in phase 1 of the next K-tile
     raw_barrier();
     mma(1, 0);
-    raw_barrier();
+    barrier_b();
   };
 
   // prologue: K-tile 0 in the order it is needed; phase 1 needs the first two half-tiles
@@ -1026,10 +1027,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   issue_half(3, 0);
   wait_vmcnt<4>();
   raw_barrier();
-  if (wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
+  if (VAR != 1 && wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
   for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
   ktile(nk - 1, std::true_type{});
-  if (wr == 0) raw_barrier();  // balance the barrier count
+  if (VAR != 1 && wr == 0) raw_barrier();  // balance the barrier count
 
   epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
   epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
@@ -1391,19 +1392,26 @@ static bool use_256(const GemmArgs& a) {
   if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
   return tiles >= 512 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.9;
 }
+static int g_256_var = 0;
+static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
+void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
+void gemm_set_256_var(int v) { g_256_var = v; }
 static int launch_256(GemmArgs a, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   a.tiles_r = a.R / 256;
   a.tiles_c = a.Cn / 256;
-  a.group_rows = g_group_rows > 1 ? (g_group_rows + 1) / 2 : 1;
+  a.group_rows = g_group_rows_256;
   a.nt_store = g_nt_store;
-  gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  if (g_256_var == 1) gemm_nt_256_kernel<1><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  else if (g_256_var == 2) gemm_nt_256_kernel<2><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  else gemm_nt_256_kernel<0><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
 static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)

@@ -18,6 +18,8 @@ void gemm_set_nt_store(int on);
 void gemm_set_persist(int on);
 void gemm_set_n112(int on);
 void gemm_set_256(int on);
+void gemm_set_256_var(int v);
+void gemm_set_group_rows_256(int g);
 void gemm_set_tn_streamk(int on);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);

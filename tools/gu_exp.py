@@ -13,9 +13,9 @@ def timeit(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for rep in range(2):
-  for stg in (0, 1, 0, 1):
+  for stg in (0, 1, 2):
     nt = stg
-    lib.slam_set_option(None, b"gemm_256", stg)
+    lib.slam_set_option(None, b"gemm_256_var", stg)
     f = timeit(lambda: lib.slam_op_gemm_nt_swiglu(x.data_ptr(), w.data_ptr(), y.data_ptr(), a.data_ptr(), M, N, K, st))
     p = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 2, st))
-    print(f"g256={nt}: fused {f:7.1f} us  plain {p:7.1f} us")
+    print(f"256-kernel variant {nt}: fused {f:7.1f} us  plain {p:7.1f} us")
