@@ -11,7 +11,7 @@ overlapped with backward) + global-norm clip 0.5 + AdamW, on synthetic unit-toke
 resident in HBM. Weak scaling (per-GPU work fixed). Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
-  roofline     - dominant kernel (the gate|up projection GEMM with fused SwiGLU, M=8192 N=9728 K=896): algorithmic flops per
+  roofline     - dominant kernel (the gate|up projection GEMM with fused SwiGLU, M=8192 N=9728 K=896, 256x256 8-phase kernel): algorithmic flops per
                  launch / mean launch time measured here with HIP events on the launch stream, against the
                  2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md). `step_frac` is the whole-step
                  figure: tokens/s x 2.282 GFLOP/token / peak.
@@ -99,13 +99,13 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<NT, LDS-DMA ring 2, 4 waves, 128x128x64> gate|up + fused SwiGLU, M8192 N9728 K896",
+    return {"bound": "mfma", "kernel": "gemm_nt_256_kernel (NT, 256x256x64 tiles, 8 waves, 8-phase LDS-DMA schedule) gate|up + fused SwiGLU, M8192 N9728 K896",
             "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
             # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes): a recorded
             # measurement of this same kernel and shape (profiles/r1_pmc_gateup_traffic.md), not collected live
-            "traffic": 677.8e6, "algorithmic_bytes": 271.2e6}
+            "traffic": 452.3e6, "algorithmic_bytes": 271.2e6}
 
 
 def usable_cores() -> int:

@@ -21,16 +21,16 @@ with open(dst, "w") as f:
 # optional: kernel_trace.csv of the same run -> GEMM launches split by grid (one kernel name serves every shape)
 if len(sys.argv) > 5:
     import collections
-    names = {4864: "gate|up fwd (+fused SwiGLU), M8192 N9728 K896  <- bench.py roofline kernel", 2432: "down dgrad (+fused SwiGLU bwd), N4864 K896",
+    names = {4864: "gate|up fwd on the 128x128 kernel", 2432: "down dgrad (+fused SwiGLU bwd), N4864 K896",
              576: "qkv fwd (+bias, RoPE), N1152 K896", 448: "N896 shapes: o fwd/dgrad, down fwd, qkv dgrad, gate|up dgrad", 256: "LM head fwd, N512"}
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(sys.argv[5])):
         n = r["Kernel_Name"]
-        if "gemm_kernel" in n or "gemm_tn_bal" in n or "gemm_nt_persist" in n:
-            kind = "wgrad (balanced TN)" if "tn_bal" in n else "NT"
+        if "gemm_kernel" in n or "gemm_tn_bal" in n or "gemm_nt_persist" in n or "gemm_nt_256" in n:
+            kind = "wgrad (balanced TN)" if "tn_bal" in n else "NT 256x256 8-phase" if "gemm_nt_256" in n else "NT"
             agg[(kind, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     with open(dst, "a") as f:
         f.write("\n## GEMM launches by grid (from the kernel trace of the same run)\n\n| kernel | blocks | launches | avg us | total ms | shape |\n|---|---|---|---|---|---|\n")
         for (kind, blocks), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-            f.write(f"| {kind} | {blocks} | {len(v)} | {sum(v)/len(v):.1f} | {sum(v)/1e3:.1f} | {names.get(blocks, '') if kind == 'NT' else ''} |\n")
+            f.write(f"| {kind} | {blocks} | {len(v)} | {sum(v)/len(v):.1f} | {sum(v)/1e3:.1f} | {names.get(blocks, '') if kind == 'NT' else 'gate|up fwd (+fused SwiGLU), M8192 N9728 K896  <- bench.py roofline kernel' if blocks == 1216 else ''} |\n")
 print(open(dst).read()[:2500])
