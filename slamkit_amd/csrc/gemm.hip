@@ -1036,6 +1036,126 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
 }
 
+// ---- 256 x 128 tiles, 8 waves, phase schedule with a three-deep K-tile ring ---------------------------------------
+// The N = 896 projections give only 7 column tiles of 128: with 256-row tiles they are 224 blocks, one per CU on 7/8 of
+// the chip - what the staggered phase schedule of gemm_nt_256_kernel needs (two waves of ONE block per SIMD), at the
+// price of 12.5 % idle CUs. Eight waves as 4 (rows) x 2 (columns), 64 x 64 of the output each (acc = 64 VGPRs, the
+// fragment / epilogue layout of gemm_kernel). A K-tile is two phases (column halves nq = 0, 1 of every wave, 16 MFMAs
+// each); its six 8 KB pieces (A rows 64j.., j = 0..3, read only by wave row j; Bq0; Bq1) are fetched TWO K-tiles ahead
+// into a ring of three 48 KB buffers, three pieces per phase, so a piece has two K-tiles of MFMA time to land and the
+// counted vmcnt (7 / 9 outstanding) never drains.
+template <int REM>  // K-tiles after this one that still have to be fetched from here on: 2 = steady state, 1, 0
+SLAM_DEVICE void wait_p128(int phase) {
+  if (phase == 0) { if (REM == 2) wait_vmcnt<9>(); else if (REM == 1) wait_vmcnt<6>(); else wait_vmcnt<0>(); }
+  else { if (REM == 2) wait_vmcnt<7>(); else if (REM == 1) wait_vmcnt<1>(); }
+}
+__global__ __launch_bounds__(512, 1) void gemm_nt_256x128_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PC = 64 * 128;  // piece: 64 rows x 128 B
+  constexpr int KT = 6 * PC;    // K-tile buffer: A0 A1 A2 A3 Bq0 Bq1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * 256, col0 = tc_ * 128;
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  // one chunk per lane per piece: lane -> (row r of the piece, swizzled chunk)
+  const int r = tid >> 3, c = (tid & 7) ^ lds_swz_key(r);
+  const uint32_t voA = (uint32_t)(((size_t)(row0 + r) * p.lda + c * 8) * sizeof(bf16_t));  // + 64 j rows via the base
+  uint32_t voB[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    voB[q] = (uint32_t)(((size_t)(col0 + (r >> 5) * 64 + perm64(q * 32 + (r & 31))) * p.ldb + c * 8) * sizeof(bf16_t));
+  auto issue_piece = [&](int j, int t) {  // j: 0..3 = A rows 64j.., 4 = Bq0, 5 = Bq1
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((t % 3) * KT + j * PC) + (uint32_t)wv * 1024u);
+    if (j < 4) glds16_sv(p.A + (size_t)j * 64 * p.lda + (size_t)t * BK, voA, dst);
+    else glds16_sv(p.B + (size_t)t * BK, voB[j - 4], dst);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ka = (l15 >> 1) & 7;
+  uint4 afr[2][4], bfr[2][2][2];
+  auto read_A = [&](const char* buf) {
+    const char* pa = buf + wm * PC;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        afr[kk][f] = *reinterpret_cast<const uint4*>(pa + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
+  };
+  auto read_B = [&](const char* buf, int nq) {
+    const char* pb = buf + (4 + nq) * PC;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(pb + (wn * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (wn * 2 + f)) & 7) << 4));
+  };
+  auto mma = [&](int nq) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) acc[fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[fm][nq * 2 + fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](int t, auto rem_tag) {
+    constexpr int REM = decltype(rem_tag)::value;
+    const char* buf = smem + (t % 3) * KT;
+    // phase 1: column half 0
+    if (REM == 2) { issue_piece(0, t + 2); issue_piece(1, t + 2); issue_piece(2, t + 2); }
+    read_A(buf);
+    read_B(buf, 0);
+    wait_p128<REM>(0);  // Bq1(t) landed -> read in phase 2
+    raw_barrier();
+    mma(0);
+    raw_barrier();
+    // phase 2: column half 1
+    if (REM == 2) { issue_piece(3, t + 2); issue_piece(4, t + 2); issue_piece(5, t + 2); }
+    read_B(buf, 1);
+    wait_p128<REM>(1);  // A and Bq0 of K-tile t+1 landed -> read in its phase 1
+    raw_barrier();
+    mma(1);
+    raw_barrier();
+  };
+#pragma unroll
+  for (int j = 0; j < 6; ++j) issue_piece(j, 0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) issue_piece(j, 1);
+  wait_vmcnt<7>();
+  raw_barrier();
+  if (wave >= 4) raw_barrier();  // waves 4..7 (the second wave of every SIMD): one barrier behind
+  for (int t = 0; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 2>{});
+  ktile(nk - 2, std::integral_constant<int, 1>{});
+  ktile(nk - 1, std::integral_constant<int, 0>{});
+  if (wave < 4) raw_barrier();
+  epilogue8(p, acc, row0, col0, wm, wn, l15, g);
+}
+
 // ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
 //      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
 //      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
@@ -1414,6 +1534,29 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   else gemm_nt_256_kernel<0><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
+static int g_gemm_256x128 = 0;  // measured equal-to-slower than 448 tiles of 128 x 128 (gate|up dgrad 143.7 vs 138.9 us): selectable
+void gemm_set_256x128(int on) { g_gemm_256x128 = on; }
+static bool use_256x128(const GemmArgs& a) {
+  if (!g_gemm_256x128 || (a.R % 256) || (a.Cn % 128) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
+  const int tiles = (a.R / 256) * (a.Cn / 128);
+  if (g_gemm_256x128 == 2) return true;  // forced (tests / A-B)
+  return tiles <= 256 && tiles >= 216 && a.Kc >= 2048;  // one round on >= 85 % of the CUs, long contraction
+}
+static int launch_256x128(GemmArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256x128_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 6 * 64 * 128);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.tiles_r = a.R / 256;
+  a.tiles_c = a.Cn / 128;
+  a.group_rows = g_group_rows_256;
+  a.nt_store = g_nt_store;
+  gemm_nt_256x128_kernel<<<a.tiles_r * a.tiles_c, 512, 3 * 6 * 64 * 128, st>>>(a);
+  return (int)hipGetLastError();
+}
 static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)
 void gemm_set_n112(int on) { g_gemm_n112 = on; }
 // 128 x 112 tiles when they fill the 512 block slots better than 128 x 128 ones (N = 896: 512 vs 448 tiles)
@@ -1457,6 +1600,7 @@ static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
   }
   if (use_n112(a0)) return launch_n112(a0, st);
   if (g_gemm_cmode == 1 && use_256(a0)) return launch_256(a0, st);
+  if (g_gemm_cmode == 1 && use_256x128(a0)) return launch_256x128(a0, st);
   const GemmArgs& a = a0;
   switch (g_gemm_cmode) {
     case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);

@@ -76,6 +76,24 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 896, 64 * 5), (2048, 384, 64 * 2), (512, 128, 64 * 9)])
+def test_gemm_nt_256x128_variant(M, N, K):
+    """The selectable 256 x 128 kernel (three-deep K-tile ring, staggered wave groups): same bits as the default,
+    for K-tile counts that exercise the 2-, 3- and many-tile paths of its tail handling."""
+    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
+    outs = []
+    for on in (0, 2):
+        assert lib().slam_set_option(None, b"gemm_256x128", on) == 0
+        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
+        sync()
+        outs.append(Y)
+    lib().slam_set_option(None, b"gemm_256x128", 0)
+    check("gemm_nt 256x128", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_nt_n112_variant():
     """The selectable 128 x 112 tiling (N = 896 -> exactly 512 tiles at M = 8192) gives the same bits as the default."""
     M, N, K = 1100, 896, 256
