@@ -32,5 +32,5 @@ if len(sys.argv) > 5:
     with open(dst, "a") as f:
         f.write("\n## GEMM launches by grid (from the kernel trace of the same run)\n\n| kernel | blocks | launches | avg us | total ms | shape |\n|---|---|---|---|---|---|\n")
         for (kind, blocks), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-            f.write(f"| {kind} | {blocks} | {len(v)} | {sum(v)/len(v):.1f} | {sum(v)/1e3:.1f} | {names.get(blocks, '') if kind == 'NT' else 'gate|up fwd (+fused SwiGLU), M8192 N9728 K896  <- bench.py roofline kernel' if blocks == 1216 else ''} |\n")
+            f.write(f"| {kind} | {blocks} | {len(v)} | {sum(v)/len(v):.1f} | {sum(v)/1e3:.1f} | {names.get(blocks, '') if kind == 'NT' else 'gate|up fwd (+fused SwiGLU), M8192 N9728 K896  <- bench.py roofline kernel' if blocks == 1216 else 'down dgrad (+fused SwiGLU bwd), N4864 K896' if blocks == 608 and '256' in kind else ''} |\n")
 print(open(dst).read()[:2500])
