@@ -280,6 +280,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss = float(trainer._loss_acc) / max(1, trainer._loss_n)
+    exposed = trainer.reducer.exposed_ms()  # last step: compute-stream stall behind the gradient all-reduce
+    if world > 1:
+        t = torch.tensor([exposed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed = float(t)
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -292,7 +297,8 @@ def main():
                                    "synthetic unit-token stream, random-init weights; full optimizer step",
                        "model": "Slam-358M", "global_batch": world * B * a.grad_accum, "micro_batch": B, "seq_len": T,
                        "grad_accum": a.grad_accum, "parallelism": f"dp{world}",
-                       "optimizer": "AdamW fp32 master+moments, clip 0.5", "final_loss": round(loss, 4)},
+                       "optimizer": "AdamW fp32 master+moments, clip 0.5", "final_loss": round(loss, 4),
+                       "exposed_comm_ms_last_step": round(exposed, 3)},
         }
         roof = dominant_kernel_roofline(model)
         roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)

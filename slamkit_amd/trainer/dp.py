@@ -60,6 +60,14 @@ class GradBucketReducer:
         # SLAM_DP_FORCE=1: run the collective path even on a single rank (exercises RCCL on a 1-GPU box)
         self.force = os.environ.get("SLAM_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
+    def exposed_ms(self) -> float:
+        """Exposed gradient-exchange time of the last finished step (synchronises on its end event); 0 on one rank."""
+        ev = getattr(self, "_exposed", None)
+        if ev is None:
+            return 0.0
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
+
     def on_bucket(self, offset: int, count: int):
         """Called by the engine (host side) right after the kernels producing grads[offset:offset+count]
         were enqueued on the current stream."""
@@ -77,11 +85,20 @@ class GradBucketReducer:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Make the compute stream wait for every outstanding bucket."""
-        for w in self.pending:
-            w.wait()
+        """Make the compute stream wait for every outstanding bucket. The stall of the compute stream (= the part of
+        the gradient exchange that backward did not hide) is bracketed by two events; `exposed_ms()` reads it."""
         if self.side is not None and self.pending:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+            cur = torch.cuda.current_stream(self.flat.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for w in self.pending:
+                w.wait()
+            cur.wait_stream(self.side)
+            e1.record(cur)
+            self._exposed = (e0, e1)
+        else:
+            for w in self.pending:
+                w.wait()
         self.pending = []
         covered = sorted(self.ranges)
         self.ranges = []

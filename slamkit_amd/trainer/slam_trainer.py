@@ -159,6 +159,7 @@ class SLAMTrainer:
         self._loss_n = 0
         dt = time.time() - t0
         rec = {"step": self.state.global_step, "loss": loss, "grad_norm": float(self.norm_out[0]), "learning_rate": lr,
+               "exposed_comm_ms": self.reducer.exposed_ms(),
                "num_input_tokens_seen": self.state.num_input_tokens_seen,
                "tokens_per_sec": (self.state.num_input_tokens_seen - tokens0) / max(dt, 1e-9)}
         self.state.log_history.append(rec)
