@@ -1696,7 +1696,7 @@ int gemm_tn_splits(int M, int N, int K) {
 }
 // balanced plan for the DMA-eligible shapes (see gemm_tn_bal_kernel)
 static int g_tn_balanced = 1;
-void gemm_set_tn_streamk(int on) { g_tn_balanced = on; }
+void gemm_set_tn_balanced(int on) { g_tn_balanced = on; }
 static const int BAL_SLOTS = 512;  // 2 blocks per CU on the 256-CU MI355X
 struct BalPlan { int T_A, S_A, per_A, SA_act, T_B, S_B, per_B, SB_act; };
 static bool tn_bal_ok(int M, int N, int K) {
