@@ -49,7 +49,7 @@ for name, (N, K) in {"wqkv": (1152, 896), "wo": (896, 896), "wgu": (9728, 896), 
     for sk in (0, 1, 0, 1):
         lib.slam_set_option(None, b"gemm_tn_balanced", sk)
         us = timeit(lambda: lib.slam_op_gemm_tn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 1, M, N, K, ws.data_ptr(), st))
-        print(f"tn {name:20s} streamk={sk} {us:9.1f} us {2.0 * M * N * K / us / 1e6:9.1f} TF (incl. reduce)")
+        print(f"tn {name:20s} balanced={sk} {us:9.1f} us {2.0 * M * N * K / us / 1e6:9.1f} TF (incl. reduce)")
     lib.slam_set_option(None, b"gemm_tn_balanced", 1)
     lib.slam_set_option(None, b"gemm_tn_splits", 0)
     lib.slam_set_option(None, b"gemm_tn_dma", 1)
