@@ -42,7 +42,7 @@ typedef struct SlamModelDesc {
   int32_t n_kv_heads;    /* 2   */
   int32_t head_dim;      /* 64 or 128 */
   int32_t intermediate;  /* 4864 */
-  int32_t vocab;         /* 502; embedding rows are padded to 512, or to a multiple of 128 beyond 512 */
+  int32_t vocab;         /* 502; embedding rows are padded to 512, or to a multiple of 256 beyond 512 */
   int32_t pad_token_id;  /* 0: nn.Embedding(padding_idx) gather-gradient suppression; -1 = none */
   float rms_eps;         /* 1e-6 */
   float rope_theta;      /* 10000 */

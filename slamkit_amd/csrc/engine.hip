@@ -42,7 +42,7 @@ __global__ void seg_fill_kernel(int* seg_start, int* seg_end, int M, int T) {
 struct SlamEngine {
   SlamModelDesc d;
   int QKV;  // (nH + 2 nKV) * hd
-  int vpad = VPAD_SMALL;  // embedding / logits rows: 512, or vocab rounded up to 128 beyond that
+  int vpad = VPAD_SMALL;  // embedding / logits rows: 512, or vocab rounded up to 256 beyond that
   int64_t n_params;
   int64_t off_embed, off_norm, layer_stride = 0;
   std::vector<LayerOff> lo;
@@ -240,7 +240,7 @@ int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   SlamEngine* e = new SlamEngine();
   e->d = d;
   e->QKV = (d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
-  e->vpad = d.vocab <= VPAD_SMALL ? VPAD_SMALL : ((d.vocab + 127) / 128) * 128;
+  e->vpad = d.vocab <= VPAD_SMALL ? VPAD_SMALL : ((d.vocab + 255) / 256) * 256;  // 256: the LM-head GEMM can take the 256 x 256 kernel
   e->fuse_swiglu = (d.hidden % 64 == 0) && ((2 * d.intermediate) % 128 == 0);
   int64_t off = 0;
   e->off_embed = off;
