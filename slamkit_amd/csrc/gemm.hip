@@ -1506,12 +1506,13 @@ static int g_gemm_256 = 1;
 void gemm_set_256(int on) { g_gemm_256 = on; }
 // the 256 x 256 kernel runs one block per CU: worth it when the tiles fill most of whole rounds of the 256 CUs
 // (gate|up forward: 1216 tiles = 4.75 rounds, 95 %; down-proj dgrad: 608 tiles = 2.4 rounds, 79 %: equal as a plain
-// GEMM, +1 % step throughput with its fused SwiGLU-backward epilogue)
+// GEMM, +1 % step throughput with its fused SwiGLU-backward epilogue; N = 1536 at M = 16384: 384 tiles = 1.5 rounds,
+// 75 %, still +4.7 % on the Qwen2.5-1.5B-shaped step because its contractions are long)
 static bool use_256(const GemmArgs& a) {
   if (!g_gemm_256 || (a.R % 256) || (a.Cn % 256) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
   const int tiles = (a.R / 256) * (a.Cn / 256);
   if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
-  return tiles >= 512 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.75;
+  return tiles >= 256 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.74;
 }
 static int g_256_var = 0;
 static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
