@@ -341,6 +341,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_n112")) { gemm_set_n112((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256x128")) { gemm_set_256x128((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_256x112")) { gemm_set_256x112((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256_var")) { gemm_set_256_var((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }

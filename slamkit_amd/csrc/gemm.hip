@@ -1156,6 +1156,154 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256x128_kernel(GemmArgs p) {
   epilogue8(p, acc, row0, col0, wm, wn, l15, g);
 }
 
+// ---- 256 x 112 tiles for the long-contraction N = 896 launches ----------------------------------------------------
+// 8192 x 896 outputs are exactly 256 tiles of 256 x 112: one block per CU on EVERY CU (256 x 128 tiles leave 32 CUs
+// idle, 128 x 128 tiles a quarter of the block slots). 112 columns = 7 MFMA fragments, split 4 + 3 between the two
+// wave columns; waves 0-3 (wave rows 0..3, 64 x 64 of the output) and waves 4-7 (64 x 48) share the SIMDs pairwise,
+// so every SIMD carries 32 + 24 MFMAs per K-tile. Otherwise gemm_nt_256x128_kernel: three-deep K-tile ring of six
+// 8 KB pieces, two phases per K-tile, second wave group one barrier behind, counted vmcnt. Four-column epilogue
+// (bias, residual): the outputs of these launches are small (14.7 MB), their contractions long.
+__global__ __launch_bounds__(512, 1) void gemm_nt_256x112_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PC = 64 * 128, KT = 6 * PC, BN2 = 112;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wm = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tr_, tc_;
+  {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    tc_ = in / rows_here;
+    tr_ = grp * GR + in - tc_ * rows_here;
+  }
+  const int row0 = tr_ * 256, col0 = tc_ * BN2;
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int r = tid >> 3, c = (tid & 7) ^ lds_swz_key(r);
+  const uint32_t voA = (uint32_t)(((size_t)(row0 + r) * p.lda + c * 8) * sizeof(bf16_t));
+  uint32_t voB[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {  // piece q: rows 0..31 = columns 32q.. of wave column 0, rows 32..63 = of wave column 1
+    int col = (r >> 5) * 64 + q * 32 + (r & 31);
+    col = col < BN2 ? col : BN2 - 1;  // wave column 1 has 48 columns: the tail rows repeat column 111 (never used)
+    voB[q] = (uint32_t)(((size_t)(col0 + col) * p.ldb + c * 8) * sizeof(bf16_t));
+  }
+  auto issue_piece = [&](int j, int t) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((t % 3) * KT + j * PC) + (uint32_t)wv * 1024u);
+    if (j < 4) glds16_sv(p.A + (size_t)j * 64 * p.lda + (size_t)t * BK, voA, dst);
+    else glds16_sv(p.B + (size_t)t * BK, voB[j - 4], dst);
+  };
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ka = (l15 >> 1) & 7;
+  uint4 afr[2][4], bfr[2][2][2];
+  auto read_A = [&](const char* buf) {
+    const char* pa = buf + wm * PC;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        afr[kk][f] = *reinterpret_cast<const uint4*>(pa + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
+  };
+  auto read_B = [&](const char* buf, int nq) {
+    const char* pb = buf + (4 + nq) * PC;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(pb + (wn * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (wn * 2 + f)) & 7) << 4));
+  };
+  auto mma = [&](int nq, auto nfn_tag) {
+    constexpr int NFN = decltype(nfn_tag)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < NFN; ++fn) acc[fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[fm][nq * 2 + fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](int t, auto rem_tag) {
+    constexpr int REM = decltype(rem_tag)::value;
+    const char* buf = smem + (t % 3) * KT;
+    if (REM == 2) { issue_piece(0, t + 2); issue_piece(1, t + 2); issue_piece(2, t + 2); }
+    read_A(buf);
+    read_B(buf, 0);
+    wait_p128<REM>(0);
+    raw_barrier();
+    mma(0, std::integral_constant<int, 2>{});
+    raw_barrier();
+    if (REM == 2) { issue_piece(3, t + 2); issue_piece(4, t + 2); issue_piece(5, t + 2); }
+    read_B(buf, 1);
+    wait_p128<REM>(1);
+    raw_barrier();
+    if (wn == 0) mma(1, std::integral_constant<int, 2>{});
+    else mma(1, std::integral_constant<int, 1>{});
+    raw_barrier();
+  };
+#pragma unroll
+  for (int j = 0; j < 6; ++j) issue_piece(j, 0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) issue_piece(j, 1);
+  wait_vmcnt<7>();
+  raw_barrier();
+  if (wave >= 4) raw_barrier();
+  for (int t = 0; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 2>{});
+  ktile(nk - 2, std::integral_constant<int, 1>{});
+  ktile(nk - 1, std::integral_constant<int, 0>{});
+  if (wave < 4) raw_barrier();
+
+  const int nfr = wn ? 3 : 4;
+  uint2 bb[4];
+  if (p.bias) {
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+      if (fn < nfr) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + wn * 64 + fn * 16 + g * 4);
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + wm * 64 + fm * 16 + l15;
+    const size_t rowoff = (size_t)m * p.ldc;
+    uint2 rr[4];
+    if (p.resid) {
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+        if (fn < nfr) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wn * 64 + fn * 16 + g * 4);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      if (fn >= nfr) continue;
+      f32x4_t v = acc[fm][fn];
+      if (p.bias) {
+        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
+      }
+      if (p.resid) {
+        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + wn * 64 + fn * 16 + g * 4) = o;
+    }
+  }
+}
+
 // ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
 //      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
 //      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
@@ -1559,6 +1707,28 @@ static int launch_256x128(GemmArgs a, hipStream_t st) {
   gemm_nt_256x128_kernel<<<a.tiles_r * a.tiles_c, 512, 3 * 6 * 64 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
+static int g_gemm_256x112 = 0;  // measured: full fill of the CUs but 976 vs 1040 TFLOP/s on the gate|up dgrad: selectable only
+void gemm_set_256x112(int on) { g_gemm_256x112 = on; }
+static bool use_256x112(const GemmArgs& a) {
+  if (!g_gemm_256x112 || (a.R % 256) || (a.Cn % 112) || (a.Kc % BK) || a.Kc < 2 * BK || a.act || a.gu || a.rope_cos) return false;
+  if (g_gemm_256x112 == 2) return true;  // forced (tests / A-B)
+  const int tiles = (a.R / 256) * (a.Cn / 112);
+  return tiles >= 224 && tiles <= 256 && a.Kc >= 2048;
+}
+static int launch_256x112(GemmArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256x112_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 6 * 64 * 128);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.tiles_r = a.R / 256;
+  a.tiles_c = a.Cn / 112;
+  a.group_rows = g_group_rows_256;
+  gemm_nt_256x112_kernel<<<a.tiles_r * a.tiles_c, 512, 3 * 6 * 64 * 128, st>>>(a);
+  return (int)hipGetLastError();
+}
 static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)
 void gemm_set_n112(int on) { g_gemm_n112 = on; }
 // 128 x 112 tiles when they fill the 512 block slots better than 128 x 128 ones (N = 896: 512 vs 448 tiles)
@@ -1603,6 +1773,7 @@ static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
   if (use_n112(a0)) return launch_n112(a0, st);
   if (g_gemm_cmode == 1 && use_256(a0)) return launch_256(a0, st);
   if (g_gemm_cmode == 1 && use_256x128(a0)) return launch_256x128(a0, st);
+  if (use_256x112(a0)) return launch_256x112(a0, st);
   const GemmArgs& a = a0;
   switch (g_gemm_cmode) {
     case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);

@@ -19,6 +19,7 @@ void gemm_set_persist(int on);
 void gemm_set_n112(int on);
 void gemm_set_256(int on);
 void gemm_set_256x128(int on);
+void gemm_set_256x112(int on);
 void gemm_set_256_var(int v);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);

@@ -94,6 +94,24 @@ def test_gemm_nt_256x128_variant(M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 896, 64 * 5), (512, 896, 64 * 2), (256, 1792, 64 * 7)])
+def test_gemm_nt_256x112_variant(M, N, K):
+    """The selectable 256 x 112 kernel (4 + 3 fragment split between the wave columns): same bits as the default."""
+    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
+    outs = []
+    for on in (0, 2):
+        assert lib().slam_set_option(None, b"gemm_256x112", on) == 0
+        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream())
+        sync()
+        assert rc == 0
+        outs.append(Y)
+    lib().slam_set_option(None, b"gemm_256x112", 0)
+    check("gemm_nt 256x112", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_nt_n112_variant():
     """The selectable 128 x 112 tiling (N = 896 -> exactly 512 tiles at M = 8192) gives the same bits as the default."""
     M, N, K = 1100, 896, 256

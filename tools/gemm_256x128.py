@@ -16,9 +16,9 @@ for name, (N, K) in {"o fwd": (896, 896), "qkv dgrad": (896, 1152), "down fwd": 
     ref = None
     for rep in range(2):
         for mode in (0, 2):
-            lib.slam_set_option(None, b"gemm_256x128", mode)
+            lib.slam_set_option(None, b"gemm_256x112", mode)
             y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
             us = timeit(lambda: lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, res.data_ptr(), M, N, K, 2, st))
             if ref is None: ref = y
-            print(f"{name:14s} 256x128={mode}: {us:8.1f} us {2.0*M*N*K/us/1e6:8.1f} TF same={torch.equal(ref, y)}", flush=True)
-lib.slam_set_option(None, b"gemm_256x128", 0)
+            print(f"{name:14s} 256x112={mode}: {us:8.1f} us {2.0*M*N*K/us/1e6:8.1f} TF same={torch.equal(ref, y)}", flush=True)
+lib.slam_set_option(None, b"gemm_256x112", 0)
