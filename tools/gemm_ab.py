@@ -1,4 +1,6 @@
-"""A/B of the experimental 128x128x32 deep-ring NT GEMM (modes 323/324/325) against mode 2."""
+"""Same-process A/B of the NT GEMM variants on the Slam-358M shapes (run on the GPU box):
+  python tools/gemm_ab.py [modes...]      modes = gemm_glds values (2 = default ring, 11, 3, 4, 322-325, 82-84, 162/163)
+  env CMODES / N112 / G256 = comma lists swept for mode 2 (column-tile layout, 128x112 tiles, 256x256 kernel)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slamkit_amd import engine as E

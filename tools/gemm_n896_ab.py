@@ -1,4 +1,5 @@
-"""A/B of the 256 x 128 three-buffer phase kernel (gemm_256x128 = 2: forced) against the default on the N = 896 shapes."""
+"""A/B of the staggered-phase kernels for the N = 896 launches (gemm_256x112 = 2: forced; edit the option key for
+gemm_256x128) against the default 128 x 128 kernel, with the residual epilogue."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slamkit_amd import engine as E
