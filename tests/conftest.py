@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The suites bind the in-tree libslam_engine.so (git-ignored): build it when a fresh checkout has none
+    (hipcc cross-compiles gfx950 without a GPU). Never falls back to anything else."""
+    lib = os.path.join(ROOT, "slamkit_amd", "lib", "libslam_engine.so")
+    if not os.path.exists(lib):
+        from slamkit_amd.csrc import build as B
+        B.build()
+
+
 @pytest.fixture(scope="session")
 def golden_npz():
     import numpy as np
