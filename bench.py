@@ -17,7 +17,7 @@ Extra objects on the line:
                  figure: tokens/s x 2.282 GFLOP/token / peak.
   cpu_baseline - the fp32 CPU oracle (oracle/slam_oracle.py, a port of the reference step: it cannot run the
                  reference's cli/train.py itself) timed on this box's host cores on a bounded
-                 sample (B=1, T=1024 fwd+bwd+AdamW).
+                 sample (B=1, T=1024 fwd+bwd+clip+AdamW, median of 3 steps after a warm-up: 10-15 s of CPU work).
 """
 import argparse
 import json
@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
-        cpu_baseline_worker(steps=1, seq=512)
+        cpu_baseline_worker(steps=3, seq=1024)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
