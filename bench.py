@@ -252,7 +252,8 @@ def main():
     args = SLAMTrainingArguments(per_device_train_batch_size=B, gradient_accumulation_steps=a.grad_accum,
                                  learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0,
                                  overlap_optimizer=os.environ.get("SLAM_OVERLAP_OPTIMIZER", "0") == "1",
-                                 overwrite_first_grad=os.environ.get("SLAM_OVERWRITE_FIRST_GRAD", "1") == "1")
+                                 overwrite_first_grad=os.environ.get("SLAM_OVERWRITE_FIRST_GRAD", "1") == "1",
+                                 ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE") or None)
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
     batches = [[synth_batch(rank, i * a.grad_accum + j, dev) for j in range(a.grad_accum)] for i in range(nb)]

@@ -50,9 +50,14 @@ def host_group():
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads: torch.Tensor, group=None):
+    def __init__(self, flat_grads: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None):
+        """comm_dtype = torch.bfloat16 exchanges the buckets in bf16 through a staging buffer, like the reference's
+        DDP does when the parameters (hence the gradients) are bf16: half the bytes on the xGMI links for two
+        conversion passes per bucket; None (default) reduces the fp32 buffer in place."""
         self.flat = flat_grads
         self.group = group
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, flat_grads.dtype) else None
+        self.stage = None
         self.rank, self.world = world_info()
         self.pending = []
         self.ranges = []
@@ -75,19 +80,32 @@ class GradBucketReducer:
         if (self.world == 1 and not self.force) or count <= 0:
             return
         view = self.flat[offset:offset + count]
+        if self.comm_dtype is not None and self.stage is None:
+            self.stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
+                if self.comm_dtype is None:
+                    self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:  # cast -> reduce -> cast back, all ordered on the side stream
+                    st = self.stage[offset:offset + count]
+                    st.copy_(view)
+                    dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(st)
+        elif self.comm_dtype is None:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            st = self.stage[offset:offset + count]
+            st.copy_(view)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(st)
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket. The stall of the compute stream (= the part of
         the gradient exchange that backward did not hide) is bracketed by two events; `exposed_ms()` reads it."""
-        if self.side is not None and self.pending:
+        if self.side is not None and (self.pending or self.comm_dtype is not None) and self.ranges:
             cur = torch.cuda.current_stream(self.flat.device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)

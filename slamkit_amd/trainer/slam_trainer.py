@@ -49,7 +49,7 @@ class SLAMTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.reducer = GradBucketReducer(model.flat_grads)
+        self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, args.ddp_comm_dtype) if getattr(args, "ddp_comm_dtype", None) else None)
         self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0

@@ -42,6 +42,15 @@ def _worker(rank, world, port, q):
         assert covered == [(0, 300), (300, 400), (700, 300)]
         assert torch.equal(flat, torch.arange(n, dtype=torch.float32) * 3)
 
+        # 2b) the same exchange through a bf16 staging buffer (ddp_comm_dtype="bfloat16"): values here are exact in bf16
+        base_b = (torch.arange(256) % 64).float()  # small integers: exact in bf16, also after the sum
+        flat_b = base_b * (rank + 1)
+        red_b = GradBucketReducer(flat_b, comm_dtype=torch.bfloat16)
+        red_b.on_bucket(128, 128)
+        red_b.on_bucket(0, 128)
+        assert red_b.finish() == [(0, 128), (128, 128)]
+        assert torch.equal(flat_b, base_b * 3)
+
         # 3) DP gradient equivalence with the oracle as the compute
         cfg = O.OracleConfig(n_layers=1, hidden=64, n_heads=1, n_kv_heads=1, head_dim=64, intermediate=128)
         sd = O.init_weights(cfg, seed=1, bias_std=0.02)
