@@ -330,12 +330,27 @@ class UnitLM(TokenLM):
         if attention_mask is not None and not attention_mask.is_cuda and not _right_padded(attention_mask):
             raise ValueError("only right-padded attention_mask is supported")
         dev = self.device
-        ids = input_ids.to(dev, torch.int64).contiguous()
-        lab = labels.to(dev, torch.int64).contiguous() if labels is not None else None
+        ids = input_ids.to(dev, torch.int64)
+        lab = labels.to(dev, torch.int64) if labels is not None else None
+        pos = position_ids.to(dev, torch.int64) if position_ids is not None else None
+        # The LDS-DMA wgrad path needs a token count that is a multiple of 64; collated batches have arbitrary lengths.
+        # Right-pad the token axis with pad ids / ignored labels (a dummy trailing segment for packed rows): under the
+        # causal mask no real token sees the padding, the loss skips it, and the extra logits rows are not returned.
+        T0 = T
+        if (B * T) % 64 and (pos is None or B == 1):
+            T = -(-T // 64) * 64
+            extra = T - T0
+            ids = torch.cat([ids, ids.new_full((B, extra), int(self.config.pad_token_id or 0))], 1)
+            if lab is not None:
+                lab = torch.cat([lab, lab.new_full((B, extra), -100)], 1)
+            if pos is not None:
+                pos = torch.cat([pos, torch.arange(extra, device=dev, dtype=torch.int64)[None]], 1)
+        ids = ids.contiguous()
+        lab = lab.contiguous() if lab is not None else None
         self._ensure_workspace(B * T)
-        seg_s = seg_e = pos = None
-        if position_ids is not None:
-            pos = position_ids.to(dev, torch.int64).contiguous()
+        seg_s = seg_e = None
+        if pos is not None:
+            pos = pos.contiguous()
             if B == 1:
                 seg_s, seg_e = self._segments(pos)
         logits = torch.empty(B, T, self.config.vocab_size, dtype=torch.bfloat16, device=dev) if return_logits else None
@@ -348,6 +363,8 @@ class UnitLM(TokenLM):
         loss = None
         if lab is not None:
             loss = _EngineLoss.apply(self._anchor, self, self._loss_buf) if torch.is_grad_enabled() else self._loss_buf.clone()
+        if logits is not None and T != T0:
+            logits = logits[:, :T0]
         return CausalLMOutput(loss=loss, logits=logits)
 
     __call__ = forward
