@@ -72,6 +72,7 @@ class SLAMDPOTrainer(SLAMTrainer):
                 seqs.append(ids)
                 labs.append(lab)
         T = max(len(s) for s in seqs)
+        T = -(-T // 64) * 64  # token count a multiple of 64: keeps the step on the LDS-DMA wgrad path (padding is masked)
         ids = torch.full((len(seqs), T), self.pad_id, dtype=torch.long)
         lab = torch.full((len(seqs), T), -100, dtype=torch.long)
         for i, (s, l) in enumerate(zip(seqs, labs)):
