@@ -164,6 +164,23 @@ def cpu_baseline(timeout_s=240):
                 "sample": f"oracle step did not finish within {timeout_s}s on this host"}
 
 
+def spawn_ranks(n: int) -> None:
+    """Re-run this script under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous, free port)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def bench_qwen1p5b(a, world, rank, dev):
     """Extra workload (not the BASELINE metric): same step loop on the configs[3]-shaped model."""
     from slamkit_amd.model import UnitLM, UnitLMConfig
@@ -232,14 +249,27 @@ def main():
         cpu_baseline_worker(steps=3, seq=1024)
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one process per GPU, the reference's own launch model:
+        # /root/reference cli/train.py:51,61 reads WORLD_SIZE / RANK set by torchrun, README.md:89)
+        return spawn_ranks(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # per-rank RCCL sanity line (stderr: stdout carries the ONE JSON line): a one-element all-reduce over the group
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        print(f"[bench] rank {dist.get_rank()}/{dist.get_world_size()} on cuda:{local} "
+              f"({torch.cuda.get_device_name(local)}): RCCL all-reduce of ones = {float(t):.0f}", file=sys.stderr, flush=True)
+        assert float(t) == float(dist.get_world_size())
 
     from slamkit_amd.model import UnitLM, UnitLMConfig
     from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments

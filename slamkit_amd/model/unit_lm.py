@@ -35,6 +35,51 @@ KNOWN_BASE_CONFIGS = {
 }
 
 
+_HF_DIM_KEYS = ("num_hidden_layers", "hidden_size", "num_attention_heads", "num_key_value_heads", "head_dim",
+                "intermediate_size", "rms_norm_eps", "rope_theta", "tie_word_embeddings", "initializer_range")
+
+
+def base_config_from_hf(c: dict) -> dict:
+    """Engine-side `base_config` from a HuggingFace Qwen2 config dict (a text-LM `config.json`, or the `base_config`
+    object the reference's UnitLMConfig serialises, unit_lm.py:63-73). transformers 4.x stores `rope_theta` at the top
+    level, 5.x under `rope_parameters`."""
+    mt = c.get("model_type", "qwen2")
+    if mt not in ("qwen2",):
+        raise ValueError(f"the engine implements the Qwen2 decoder family only (model_type={mt!r})")
+    if c.get("hidden_act", "silu") != "silu":
+        raise ValueError(f"unsupported hidden_act {c.get('hidden_act')!r}")
+    if c.get("use_sliding_window"):
+        raise ValueError("sliding-window attention is not supported")
+    out = {k: c[k] for k in _HF_DIM_KEYS if k in c and c[k] is not None}
+    rp = c.get("rope_parameters") or c.get("rope_scaling") or {}
+    if "rope_theta" not in out and isinstance(rp, dict) and rp.get("rope_theta") is not None:
+        out["rope_theta"] = rp["rope_theta"]
+    if isinstance(rp, dict) and rp.get("rope_type", rp.get("type", "default")) not in ("default", None):
+        raise ValueError(f"unsupported rope scaling {rp}")
+    return out
+
+
+def read_hf_weights(path: str) -> Dict[str, torch.Tensor]:
+    """All tensors of a HuggingFace checkpoint directory: `model.safetensors`, the sharded form behind
+    `model.safetensors.index.json`, or `pytorch_model.bin`."""
+    from safetensors.torch import load_file
+    one = os.path.join(path, "model.safetensors")
+    idx = one + ".index.json"
+    if os.path.exists(one):
+        return load_file(one)
+    if os.path.exists(idx):
+        with open(idx) as f:
+            shards = sorted(set(json.load(f)["weight_map"].values()))
+        sd: Dict[str, torch.Tensor] = {}
+        for sh in shards:
+            sd.update(load_file(os.path.join(path, sh)))
+        return sd
+    b = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(b):
+        return torch.load(b, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"no model.safetensors / model.safetensors.index.json / pytorch_model.bin under {path}")
+
+
 @dataclass
 class UnitLMConfig:
     """unit_lm.py:32-79. `base_config` is a dict of Qwen2Config-named fields (or None to look
@@ -57,11 +102,18 @@ class UnitLMConfig:
                  use_cache=False, pad_token_id=0, bos_token_id=1, eos_token_id=1, torch_dtype="bfloat16",
                  attn_implementation="flash_attention_2", max_tokens=8192, **kwargs):
         self.base_model_name = base_model_name
+        local_dir = isinstance(base_model_name, str) and os.path.isfile(os.path.join(base_model_name, "config.json"))
         if base_config is None:
-            if base_model_name not in KNOWN_BASE_CONFIGS:
-                raise ValueError(f"unknown base model {base_model_name!r}: pass base_config=dict(...) "
-                                 f"(no hub access); known: {sorted(KNOWN_BASE_CONFIGS)}")
-            base_config = dict(KNOWN_BASE_CONFIGS[base_model_name])
+            if local_dir:  # "could use a huggingface model name or a path to a model" (unit_lm.py:47)
+                with open(os.path.join(base_model_name, "config.json")) as f:
+                    base_config = base_config_from_hf(json.load(f))
+            elif base_model_name in KNOWN_BASE_CONFIGS:
+                base_config = dict(KNOWN_BASE_CONFIGS[base_model_name])
+            else:
+                raise ValueError(f"unknown base model {base_model_name!r}: pass a local HuggingFace directory or "
+                                 f"base_config=dict(...) (no hub access); known: {sorted(KNOWN_BASE_CONFIGS)}")
+        elif "model_type" in base_config or "rope_parameters" in base_config:
+            base_config = base_config_from_hf(base_config)  # the reference's serialised Qwen2Config
         base_config = dict(base_config)
         for k in list(kwargs):
             if k in ("rope_theta", "rms_norm_eps", "initializer_range"):
@@ -77,8 +129,9 @@ class UnitLMConfig:
         self.base_config = base_config
         self.vocab_size = vocab_size
         self.twist_init = twist_init
-        if twist_init:
-            raise ValueError("twist_init needs hub weights; load a converted checkpoint with from_pretrained instead")
+        if twist_init and not local_dir:
+            raise ValueError(f"twist_init=True loads the text LM's weights (unit_lm.py:94-98): base_model_name must be a "
+                             f"local HuggingFace checkpoint directory (the hub is unreachable), got {base_model_name!r}")
         self.use_cache = use_cache
         self.pad_token_id, self.bos_token_id, self.eos_token_id = pad_token_id, bos_token_id, eos_token_id
         self.torch_dtype = torch_dtype
@@ -90,7 +143,7 @@ class UnitLMConfig:
 
     def to_dict(self):
         return dict(model_type="speech_language_model", engine="slamkit_amd", base_model_name=self.base_model_name,
-                    base_config=self.base_config, vocab_size=self.vocab_size, pad_token_id=self.pad_token_id,
+                    base_config=self.base_config, vocab_size=self.vocab_size, twist_init=False, pad_token_id=self.pad_token_id,
                     bos_token_id=self.bos_token_id, eos_token_id=self.eos_token_id, torch_dtype=self.torch_dtype,
                     max_tokens=self.max_tokens)
 
@@ -135,7 +188,8 @@ class UnitLM(TokenLM):
     """unit_lm.py:82-212 on the HIP engine."""
     base_model_prefix = "lm"
 
-    def __init__(self, config: UnitLMConfig, device: Optional[str] = None, seed: int = 0, allocate_grads: bool = True):
+    def __init__(self, config: UnitLMConfig, device: Optional[str] = None, seed: int = 0, allocate_grads: bool = True,
+                 _from_pretrained: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("slamkit_amd.UnitLM needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.config = config
@@ -167,6 +221,9 @@ class UnitLM(TokenLM):
         self.training = True
         self._build_key_map()
         self.init_weights(seed)
+        if config.twist_init and not _from_pretrained:
+            # TWIST: start from the text LM's weights, keep the first vocab_size embedding rows (unit_lm.py:94-102)
+            self.load_hf_text_lm(config.base_model_name)
 
     # ---- layout ------------------------------------------------------------------------------
     def _build_key_map(self):
@@ -271,22 +328,56 @@ class UnitLM(TokenLM):
         src = self.flat_master if dtype == torch.float32 else self.flat_params
         return {k: self._view(src, k).detach().to(dtype).cpu().clone() for k in self.key_map}
 
+    @staticmethod
+    def _canonical_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Key layouts accepted: the UnitLM layout `lm.model.*` (reference and engine checkpoints) and a raw
+        HuggingFace causal LM's `model.*` / `lm_head.weight` (text-LM weights for TWIST initialisation)."""
+        if any(k.startswith("lm.") for k in sd):
+            return dict(sd)
+        return {("lm." + k if k.startswith(("model.", "lm_head.")) else k): v for k, v in sd.items()}
+
     @torch.no_grad()
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Copies the tensors into the fp32 master and refreshes the bf16 images. The tied `lm_head.weight` is accepted and
+        ignored. The embedding follows `resize_token_embeddings` (unit_lm.py:102): a longer matrix is cut to the first
+        vocab_size rows; a shorter one fills the new rows with the mean of the old rows (transformers' mean-resizing
+        draws them from N(mean, 1e-9 * cov): within 1e-5 of the mean). Returns (missing, unexpected); with `strict`
+        either being non-empty raises."""
         self.engine.join()
+        sd = self._canonical_keys(sd)
         missing = [k for k in self.key_map if k not in sd]
         extra = [k for k in sd if k not in self.key_map and not k.endswith("lm_head.weight")]
         if strict and (missing or extra):
-            raise KeyError(f"state_dict mismatch: missing={missing[:4]} unexpected={extra[:4]}")
+            raise KeyError(f"state_dict mismatch: {len(missing)} missing (first: {missing[:4]}), "
+                           f"{len(extra)} unexpected (first: {extra[:4]})")
         for k in self.key_map:
             if k in sd:
                 src = sd[k]
-                nrow = self.key_map[k][1][0]
-                if k == "lm.model.embed_tokens.weight" and src.shape[0] > nrow:
-                    src = src[:nrow]  # resize_token_embeddings keeps the first V rows (unit_lm.py:102)
+                shp = self.key_map[k][1]
+                if k == "lm.model.embed_tokens.weight" and src.shape[0] != shp[0]:
+                    if src.shape[0] > shp[0]:
+                        src = src[:shp[0]]
+                    else:
+                        src = torch.cat([src.float(), src.float().mean(0, keepdim=True).expand(shp[0] - src.shape[0], -1)])
+                if tuple(src.shape) != tuple(shp):
+                    raise ValueError(f"{k}: checkpoint shape {tuple(src.shape)} != model shape {tuple(shp)}")
                 self._assign(self.flat_master, k, src)
         self.sync_params_from_master()
         return missing, extra
+
+    def load_hf_text_lm(self, path: str):
+        """TWIST initialisation (unit_lm.py:94-102): every weight of a local HuggingFace Qwen2 text LM, embedding rows
+        resized to vocab_size. The text LM must tie its head (an untied `lm_head` would be dropped silently)."""
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        if not c.get("tie_word_embeddings", True):
+            raise ValueError("the engine supports tied embeddings only; this text LM has an untied lm_head")
+        want = base_config_from_hf(c)
+        for k in ("num_hidden_layers", "hidden_size", "num_attention_heads", "num_key_value_heads", "intermediate_size"):
+            if want.get(k) != self.config.base_config.get(k):
+                raise ValueError(f"text LM {k}={want.get(k)} != model {k}={self.config.base_config.get(k)}")
+        self.load_state_dict(read_hf_weights(path), strict=True)
+        return self
 
     def get_input_embeddings(self):
         return self._view(self.flat_params, "lm.model.embed_tokens.weight")
@@ -327,7 +418,8 @@ class UnitLM(TokenLM):
         token's output, so the engine does not read it."""
         assert input_ids is not None and input_ids.dim() == 2
         B, T = input_ids.shape
-        if attention_mask is not None and not attention_mask.is_cuda and not _right_padded(attention_mask):
+        if attention_mask is not None and not _right_padded(attention_mask):
+            # checked for device masks too (one small host read): a left-padded mask would otherwise be ignored silently
             raise ValueError("only right-padded attention_mask is supported")
         dev = self.device
         ids = input_ids.to(dev, torch.int64)
@@ -466,13 +558,31 @@ class UnitLM(TokenLM):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, **kwargs) -> "UnitLM":
-        from safetensors.torch import load_file
-        with open(os.path.join(pretrained_model_name_or_path, "config.json")) as f:
+        """Loads a checkpoint directory written by this engine, by the reference's `UnitLM.save_pretrained`
+        (unit_lm.py:200-212: `config.json` with a serialised Qwen2Config under `base_config`, weights under `lm.model.*`)
+        or - as a convenience for converted text LMs - a raw HuggingFace Qwen2 directory (`model.*` keys; pass
+        vocab_size= to resize). Every parameter must be present in the file: a mismatching layout raises instead of
+        leaving the model at its random initialisation."""
+        path = pretrained_model_name_or_path
+        with open(os.path.join(path, "config.json")) as f:
             c = json.load(f)
-        cfg = UnitLMConfig(base_model_name=c.get("base_model_name", "local"), base_config=c["base_config"],
-                           vocab_size=c["vocab_size"], pad_token_id=c.get("pad_token_id", 0),
-                           bos_token_id=c.get("bos_token_id", 1), eos_token_id=c.get("eos_token_id", 1),
+        vocab = kwargs.pop("vocab_size", None)
+        if "base_config" in c:
+            base = c["base_config"]
+            name = c.get("base_model_name", "local")
+        elif c.get("model_type") == "qwen2":
+            base, name = c, path
+        else:
+            raise ValueError(f"{path}/config.json is neither a UnitLM config (no `base_config`) nor a Qwen2 config "
+                             f"(model_type={c.get('model_type')!r})")
+        if not (isinstance(name, str) and (name in KNOWN_BASE_CONFIGS or os.path.isdir(name))):
+            name = "local"  # e.g. a hub id or a path of the machine that wrote the checkpoint: the dims are in base_config
+        cfg = UnitLMConfig(base_model_name=name, base_config=base,
+                           vocab_size=vocab if vocab is not None else c["vocab_size"],
+                           pad_token_id=c.get("pad_token_id", base.get("pad_token_id", 0)),
+                           bos_token_id=c.get("bos_token_id", base.get("bos_token_id", 1)),
+                           eos_token_id=c.get("eos_token_id", base.get("eos_token_id", 1)),
                            max_tokens=kwargs.pop("max_tokens", c.get("max_tokens", 8192)))
-        m = cls(cfg, **kwargs)
-        m.load_state_dict(load_file(os.path.join(pretrained_model_name_or_path, "model.safetensors")), strict=False)
+        m = cls(cfg, _from_pretrained=True, **kwargs)
+        m.load_state_dict(read_hf_weights(path), strict=True)
         return m

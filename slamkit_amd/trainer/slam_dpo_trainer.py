@@ -53,12 +53,13 @@ class SLAMDPOTrainer(SLAMTrainer):
     def __init__(self, model=None, ref_model=None, args: DPOConfig = None, train_dataset=None, eval_dataset=None,
                  processing_class=None, callbacks=None):
         args = args or DPOConfig()
-        rows = [self.tokenize_row(r, processing_class, args.max_prompt_length, args.max_completion_length)
-                for r in train_dataset]
-        super().__init__(model=model, args=args, data_collator=self._collate_pairs, train_dataset=rows,
-                         eval_dataset=eval_dataset, processing_class=processing_class, callbacks=callbacks)
+        tok = lambda ds: None if ds is None else [  # noqa: E731
+            self.tokenize_row(r, processing_class, args.max_prompt_length, args.max_completion_length) for r in ds]
+        super().__init__(model=model, args=args, data_collator=self._collate_pairs, train_dataset=tok(train_dataset),
+                         eval_dataset=tok(eval_dataset), processing_class=processing_class, callbacks=callbacks)
         self.ref_model = ref_model
         self.pad_id = model.config.pad_token_id
+        self._loss_is_rank_mean = True  # each rank accumulates the mean DPO loss of its own pairs
 
     def _collate_pairs(self, rows: List[Dict[str, List[int]]]) -> Dict[str, torch.Tensor]:
         """[chosen rows; rejected rows], right-padded; labels = completion tokens only (prompt and pad -> -100)."""
@@ -105,8 +106,13 @@ class SLAMDPOTrainer(SLAMTrainer):
                                               bucket_layers=a.ddp_bucket_layers if (last and self.world > 1) else 0,
                                               bucket_cb=self.reducer.on_bucket if (last and self.world > 1) else None)
             self._loss_acc += losses.mean().detach() / nm
-            self.state.num_input_tokens_seen += int((lab != -100).sum()) * self.world
         self._loss_n += 1
+        seen = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
+        if self.world > 1:  # the real count over ranks (host-side group; one tiny collective per optimizer step)
+            t = torch.tensor([seen], dtype=torch.float64, device="cpu" if self.host_group is not None else self.model.device)
+            torch.distributed.all_reduce(t, group=self.host_group)
+            seen = float(t)
+        self.state.num_input_tokens_seen += int(seen)
         self.reducer.finish()
         eng = self.model.engine
         eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
@@ -114,3 +120,37 @@ class SLAMDPOTrainer(SLAMTrainer):
         eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
                        a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=True)
         self.state.global_step += 1
+
+    @torch.no_grad()
+    def evaluate(self, dataset=None) -> Dict[str, float]:
+        """DPO validation: mean sigmoid-DPO loss, reward accuracy (chosen reward > rejected reward) and reward margin over
+        the tokenised validation pairs - what TRL's DPOTrainer reports as eval_loss / eval_rewards/accuracies /
+        eval_rewards/margins (restated from the definitions; rewards = beta * (policy logp - reference logp))."""
+        from .dp import shard_batches
+        ds = dataset if dataset is not None else self.eval_dataset
+        if ds is None or len(ds) == 0:
+            return {}
+        if len(ds) and "prompt_input_ids" not in ds[0]:
+            ds = [self.tokenize_row(r, self.processing_class, self.args.max_prompt_length, self.args.max_completion_length)
+                  for r in ds]
+        bs = self.args.per_device_eval_batch_size
+        idx = list(range(len(ds)))
+        batches = shard_batches([idx[i:i + bs] for i in range(0, len(idx), bs)], self.rank, self.world, even=False)
+        acc = torch.zeros(4, dtype=torch.float64, device=self.model.device)  # loss sum, correct, margin sum, pairs
+        for b in batches:
+            mb = self._collate_pairs([ds[i] for i in b])
+            ids, lab = mb["input_ids"], mb["labels"]
+            n = ids.shape[0] // 2
+            ref, _ = self.ref_model.sequence_logps(ids, lab)
+            ref = ref.clone()
+            pol, _ = self.model.sequence_logps(ids, lab)
+            losses, x = self.dpo_loss(pol[:n], pol[n:], ref[:n], ref[n:], self.args.beta)
+            acc += torch.stack([losses.sum(), (x > 0).sum().to(losses.dtype), x.sum(), x.new_tensor(float(n))]).double()
+        if self.world > 1:
+            torch.distributed.all_reduce(acc)
+        tot = acc.tolist()
+        k = max(tot[3], 1.0)
+        res = {"eval_loss": tot[0] / k, "eval_rewards/accuracies": tot[1] / k, "eval_rewards/margins": tot[2] / k,
+               "step": self.state.global_step}
+        self.state.log_history.append(res)
+        return res

@@ -53,6 +53,7 @@ class SLAMTrainer:
         self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
+        self._loss_is_rank_mean = False  # subclasses whose per-rank loss is a local mean (DPO) set this
         self.opt_step = 0
         # engine option: AdamW + weight-image refresh in per-layer chunks on the engine's side stream; slam_forward
         # waits per layer. Everything that reads the flat buffers with torch goes through UnitLM (which joins first).
@@ -139,7 +140,9 @@ class SLAMTrainer:
                 self.model.engine.set_option("grad_overwrite_next", 1)
             loss = self.training_step(self.model, mb, num_items_in_batch=n_items, last_micro=(i == len(micro) - 1),
                                       grad_scale=scale)
-            self._loss_acc += loss if a.average_tokens_across_devices else loss / len(micro)
+            # every micro-batch loss is already normalised by the whole step's token count (global, or this rank's
+            # when average_tokens_across_devices is off): their plain sum is the step's loss
+            self._loss_acc += loss
         self._loss_n += 1
         self.reducer.finish()
         self.state.num_input_tokens_seen += int(glob_seen)
@@ -150,11 +153,27 @@ class SLAMTrainer:
                        a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=not a.overwrite_first_grad)
         self.state.global_step += 1
 
+    def _sync_control(self):
+        """Callbacks decide from rank-local clocks (RunTimeStopperCallback: `start_time` differs per rank), and
+        evaluate() / save_checkpoint() contain collectives: every rank must take the SAME stop / evaluate / save
+        decision at the same step. One MAX all-reduce of the three flags, on the host (gloo) group when there is one
+        so that the step loop does not synchronise with the device."""
+        c = self.control
+        if self.host_group is not None:
+            t = torch.tensor([float(c.should_training_stop), float(c.should_evaluate), float(c.should_save)])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_group)
+        else:
+            t = torch.tensor([float(c.should_training_stop), float(c.should_evaluate), float(c.should_save)],
+                             device=self.model.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = t.cpu()
+        c.should_training_stop, c.should_evaluate, c.should_save = (bool(x > 0) for x in t.tolist())
+
     def _log(self, lr: float, t0: float, tokens0: int):
         loss_local = float(self._loss_acc) / max(1, self._loss_n)
         loss = all_reduce_scalar(loss_local, device=self.model.device) if self.world > 1 else loss_local
-        if not self.args.average_tokens_across_devices and self.world > 1:
-            loss /= self.world
+        if (not self.args.average_tokens_across_devices or self._loss_is_rank_mean) and self.world > 1:
+            loss /= self.world  # each rank accumulated its own mean: report the mean over ranks
         self._loss_acc.zero_()
         self._loss_n = 0
         dt = time.time() - t0
@@ -195,9 +214,8 @@ class SLAMTrainer:
                 self.state.epoch = self.state.global_step / updates_per_epoch
                 for cb in self.callbacks:
                     cb.on_step_end(a, self.state, self.control)
-                if self.world > 1 and self.callbacks:  # a wall-clock stop must be taken by every rank together
-                    flag = all_reduce_scalar(1.0 if self.control.should_training_stop else 0.0, device=self.model.device)
-                    self.control.should_training_stop = flag > 0
+                if self.world > 1 and self.callbacks:
+                    self._sync_control()
                 if a.logging_steps and self.state.global_step % a.logging_steps == 0:
                     self._log(lr, t0, tokens0)
                 if (a.eval_strategy == "steps" and a.eval_steps and self.state.global_step % a.eval_steps == 0) \
