@@ -32,6 +32,13 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    # train.py:18-22: interleaved data must be tokenised with the text tokeniser of the model it feeds
+    if cfg.tokeniser.get("tokeniser_type") == "interleave":
+        want = cfg.model.config_args.get("base_model_name")
+        have = cfg.tokeniser.params.get("text_tokeniser_path")
+        if have != want:
+            logger.warning(f"Text tokeniser {have}, doesn't match model changing it to: {want}")
+            cfg.tokeniser.params["text_tokeniser_path"] = want
     # train.py:25-28
     if cfg.get("train_max_tokens") is not None and (cfg.get("ds_token_size") or 0) > 0:
         cfg.training_args.num_train_epochs = (cfg.train_max_tokens / cfg.ds_token_size) * 1.01

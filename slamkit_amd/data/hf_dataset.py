@@ -64,24 +64,35 @@ class TokenDataset:
         return sum(len(r["input_ids"]) for r in self.rows)
 
 
-# ---- binary shard format: tokens.bin (uint16 LE, all sequences back to back) + index.npy (int64
-#      offsets, n+1 entries) + meta.json. ids = unit + 2 exactly as UnitTokeniser produces them. -----
+# ---- binary shard format: tokens.bin (little-endian uint16, or uint32 when an id does not fit - the interleaved
+#      speech-text vocabulary reaches 152,166; all sequences back to back) + index.npy (int64 offsets, n+1 entries) +
+#      meta.json (records the dtype). ids = unit + 2 exactly as UnitTokeniser produces them. ---------------------------
 def write_token_shard(path: str, dataset) -> None:
-    os.makedirs(path, exist_ok=True)
-    lens = np.fromiter((len(dataset[i]["input_ids"]) for i in range(len(dataset))), dtype=np.int64, count=len(dataset))
-    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    n = len(dataset)
+    lens = np.fromiter((len(dataset[i]["input_ids"]) for i in range(n)), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(lens, out=off[1:])
-    buf = np.empty(int(off[-1]), dtype="<u2")
-    for i in range(len(dataset)):
-        ids = dataset[i]["input_ids"]
-        if len(ids) and (max(ids) > 65535 or min(ids) < 0):
-            raise ValueError("token id does not fit uint16")
-        buf[off[i]:off[i + 1]] = ids
-    buf.tofile(os.path.join(path, "tokens.bin"))
-    np.save(os.path.join(path, "index.npy"), off)
-    with open(os.path.join(path, "meta.json"), "w") as f:
-        json.dump({"format": "slam-token-shard-v1", "dtype": "uint16", "sequences": int(len(lens)),
-                   "tokens": int(off[-1])}, f)
+    buf = np.empty(int(off[-1]), dtype=np.int64)
+    for i in range(n):
+        buf[off[i]:off[i + 1]] = dataset[i]["input_ids"]
+    if buf.size and int(buf.min()) < 0:
+        raise ValueError("negative token id")
+    top = int(buf.max()) if buf.size else 0
+    if top > 0xFFFFFFFF:
+        raise ValueError("token id does not fit uint32")
+    dt = "uint16" if top <= 0xFFFF else "uint32"
+    # written next to the target and renamed into place: a reader (or a concurrent rank) never sees half a shard
+    tmp = f"{path}.tmp{os.getpid()}"
+    os.makedirs(tmp, exist_ok=True)
+    buf.astype("<u2" if dt == "uint16" else "<u4").tofile(os.path.join(tmp, "tokens.bin"))
+    np.save(os.path.join(tmp, "index.npy"), off)
+    with open(os.path.join(tmp, "meta.json"), "w") as f:
+        json.dump({"format": "slam-token-shard-v1", "dtype": dt, "sequences": int(n), "tokens": int(off[-1])}, f)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if os.path.isdir(path):
+        import shutil
+        shutil.rmtree(path)
+    os.rename(tmp, path)
 
 
 class TokenShardDataset:
@@ -89,7 +100,14 @@ class TokenShardDataset:
 
     def __init__(self, path: str):
         self.off = np.load(os.path.join(path, "index.npy"))
-        self.tok = np.memmap(os.path.join(path, "tokens.bin"), dtype="<u2", mode="r")
+        dt = "uint16"
+        meta = os.path.join(path, "meta.json")
+        if os.path.exists(meta):
+            with open(meta) as f:
+                dt = json.load(f).get("dtype", "uint16")
+        if dt not in ("uint16", "uint32"):
+            raise ValueError(f"{path}: unknown shard dtype {dt!r}")
+        self.tok = np.memmap(os.path.join(path, "tokens.bin"), dtype="<u2" if dt == "uint16" else "<u4", mode="r")
         assert int(self.off[-1]) == self.tok.shape[0]
 
     def __len__(self):
@@ -182,29 +200,49 @@ def parse_single_dataset(cfg, tokeniser, train_path: str, val_path: Optional[str
     return out
 
 
-def interleave_datasets(datasets: List[TokenDataset], probabilities: List[float], seed: int = 0,
-                        stopping_strategy: str = "first_exhausted") -> TokenDataset:
-    """Seeded probabilistic interleave (datasets.interleave_datasets semantics, seed 0 at hf_dataset.py:50)."""
+def interleave_indices(lengths: Sequence[int], probabilities: Optional[Sequence[float]], seed: Optional[int] = 0,
+                       stopping_strategy: str = "first_exhausted") -> List[Tuple[int, int]]:
+    """(dataset, row) pairs in the order `datasets.interleave_datasets` selects them for map-style datasets
+    (site-packages datasets/arrow_dataset.py `_interleave_map_style_datasets`; called at hf_dataset.py:44-55 with
+    seed=0): source ids are drawn 1000 at a time from np.random.default_rng(seed).choice(n, size=1000, p=probabilities);
+    a source that runs out is flagged exhausted and restarts from its first row; the walk stops BEFORE the draw that
+    follows the stopping condition (any source exhausted / all sources exhausted). Pinned against the library by
+    tests/golden/interleave_ds.json."""
+    n = len(lengths)
+    if stopping_strategy not in ("first_exhausted", "all_exhausted", "all_exhausted_without_replacement"):
+        raise ValueError(f"{stopping_strategy} is not supported")
+    lengths = [int(x) for x in lengths]
+    if probabilities is None:
+        if stopping_strategy == "first_exhausted":
+            return [(k, i) for i in range(min(lengths)) for k in range(n)]
+        if stopping_strategy == "all_exhausted":
+            return [(k, i % lengths[k]) for i in range(max(lengths)) for k in range(n)]
+        return [(k, i) for i in range(max(lengths)) for k in range(n) if i < lengths[k]]
+    exhausted = np.full(n, False)
+    done = np.any if stopping_strategy == "first_exhausted" else np.all
+    without_replacement = stopping_strategy == "all_exhausted_without_replacement"
     rng = np.random.default_rng(seed)
-    idx = [0] * len(datasets)
-    seen_all = [False] * len(datasets)
-    rows = []
-    p = np.asarray(probabilities, dtype=np.float64)
-    p = p / p.sum()
+    cur = [0] * n
+    out: List[Tuple[int, int]] = []
     while True:
-        k = int(rng.choice(len(datasets), p=p))
-        if idx[k] >= len(datasets[k]):
-            if stopping_strategy == "first_exhausted":
-                break
-            seen_all[k] = True
-            if all(seen_all):
-                break
-            idx[k] = 0
-        rows.append(datasets[k][idx[k]])
-        idx[k] += 1
-        if stopping_strategy == "first_exhausted" and any(i >= len(d) for i, d in zip(idx, datasets)):
-            break
-    return TokenDataset(rows)
+        for k in rng.choice(n, size=1000, p=probabilities):
+            k = int(k)
+            if done(exhausted):
+                return out
+            if not without_replacement or not exhausted[k]:
+                out.append((k, cur[k]))
+                cur[k] += 1
+            if cur[k] >= lengths[k]:
+                exhausted[k] = True
+                if not without_replacement:
+                    cur[k] = 0
+
+
+def interleave_datasets(datasets: List[TokenDataset], probabilities: Optional[List[float]] = None, seed: Optional[int] = 0,
+                        stopping_strategy: str = "first_exhausted") -> TokenDataset:
+    """datasets.interleave_datasets on in-memory TokenDatasets: same rows in the same order (interleave_indices)."""
+    order = interleave_indices([len(d) for d in datasets], probabilities, seed, stopping_strategy)
+    return TokenDataset([datasets[k][i] for k, i in order])
 
 
 def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
@@ -238,9 +276,14 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
         else:
             dataset = parse_single_dataset(cfg, tokeniser, tp, _get(data, "val_path"))
         if saved:
-            logger.info(f"Saving dataset to {saved}")
-            for s, d in dataset.items():
-                write_token_shard(os.path.join(saved, s), d)
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if not multi or dist.get_rank() == 0:  # one writer; the other ranks wait, then every rank maps the shards
+                logger.info(f"Saving dataset to {saved}")
+                for s, d in dataset.items():
+                    write_token_shard(os.path.join(saved, s), d)
+            if multi:
+                dist.barrier()
     if _get(data, "packing", False):
         collator = DataCollatorWithFlattening(return_tensors="pt")
     else:
@@ -248,13 +291,49 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
     return dataset, collator
 
 
+_WORD_RE = None
+
+
+def word_tokenize(text: str) -> List[str]:
+    """Word splitter for the auto-BLEU repetition filter. The reference uses nltk's NLTKWordTokenizer (Treebank rules,
+    calculation_utils.py:32-35); nltk is not installed here, so its effect on transcript-like text is restated:
+    punctuation becomes its own token, English clitics split off ("don't" -> "do", "n't"; "it's" -> "it", "'s").
+    On punctuation-free ASR transcripts this equals whitespace splitting. Parity unpinned (no nltk to compare with)."""
+    global _WORD_RE
+    import re
+    if _WORD_RE is None:
+        _WORD_RE = re.compile(r"n't\b|'(?:s|m|d|ll|re|ve)\b|\w+?(?=n't\b)|\w+|[^\w\s]", re.IGNORECASE)
+    return _WORD_RE.findall(text)
+
+
+def calc_ngram(text: str, n: int) -> List[str]:
+    tokens = word_tokenize(text)
+    return [" ".join(tokens[i:i + n]) for i in range(len(tokens) - n + 1)]
+
+
+def calc_auto_bleu(text: str, n: int) -> float:
+    """Fraction of n-grams that occur more than once in the text (slamkit/utils/calculation_utils.py:37-47)."""
+    ngrams = calc_ngram(text, n)
+    if not ngrams:
+        return 0
+    from collections import Counter
+    cnt = Counter(ngrams)
+    return sum(1 for g in ngrams if cnt[g] > 1) / len(ngrams)
+
+
+def get_repetition_filter_fn(auto_bleu_n: int, max_auto_bleu: float):
+    """hf_dataset.py:125-133: keep a pair when auto-BLEU(prompt_text + " " + chosen_text) < max_auto_bleu."""
+    return lambda x: calc_auto_bleu(x["prompt_text"] + " " + x["chosen_text"], auto_bleu_n) < max_auto_bleu
+
+
 def init_preference_optimization_dataset(cfg) -> Dict[str, List[Dict[str, str]]]:
-    """hf_dataset.py:138-148 (the auto-BLEU repetition filter needs nltk - absent - and is skipped with a warning)."""
-    out = {"train": [dict(prompt=r["prompt"], chosen=r["chosen"], rejected=r["rejected"])
-                     for r in _read_jsonl(glob(_get(cfg, "train_path")))]}
-    if _get(cfg, "val_path", None) is not None:
-        out["validation"] = [dict(prompt=r["prompt"], chosen=r["chosen"], rejected=r["rejected"])
-                             for r in _read_jsonl(glob(_get(cfg, "val_path")))]
+    """hf_dataset.py:138-148: jsonl rows -> optional repetition filter (on the raw rows, which carry prompt_text /
+    chosen_text) -> only the prompt / chosen / rejected columns."""
+    keep = (lambda x: True)
     if _get(cfg, "repetition_filter", False):
-        logger.warning("repetition_filter needs nltk (not installed); rows are kept unfiltered")
+        keep = get_repetition_filter_fn(int(_get(cfg, "auto_bleu_n", 2)), float(_get(cfg, "max_auto_bleu", 0.3)))
+    cols = lambda rows: [dict(prompt=r["prompt"], chosen=r["chosen"], rejected=r["rejected"]) for r in rows if keep(r)]  # noqa: E731
+    out = {"train": cols(_read_jsonl(glob(_get(cfg, "train_path"))))}
+    if _get(cfg, "val_path", None) is not None:
+        out["validation"] = cols(_read_jsonl(glob(_get(cfg, "val_path"))))
     return out

@@ -232,7 +232,8 @@ class SLAMTrainer:
             self._log(a.learning_rate * lr_lambda(a, max(self.state.global_step - 1, 0), max_steps), t0, tokens0)
         for cb in self.callbacks:
             cb.on_train_end(a, self.state, self.control)
-        torch.cuda.synchronize(self.model.device)
+        if torch.device(self.model.device).type == "cuda":
+            torch.cuda.synchronize(self.model.device)
         self.model.engine.join()  # a pending overlapped optimizer step: order it before whatever the caller does next
         return self.state
 

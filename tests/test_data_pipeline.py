@@ -102,15 +102,50 @@ def test_binary_shard_roundtrip_and_saved_ds_path(golden_data, tmp_path):
     assert raw[:6].tolist() == [1, 5, 51, 9, 256, 32]  # <S> + unit+2
 
 
-def test_interleave_datasets_is_seeded_and_stops_first_exhausted():
-    a = TokenDataset([{"input_ids": [i], "attention_mask": [1]} for i in range(10)])
-    b = TokenDataset([{"input_ids": [100 + i], "attention_mask": [1]} for i in range(4)])
-    x = interleave_datasets([a, b], [0.5, 0.5], seed=0)
-    y = interleave_datasets([a, b], [0.5, 0.5], seed=0)
-    assert x.rows == y.rows
-    na = sum(1 for r in x.rows if r["input_ids"][0] < 100)
-    nb = len(x) - na
-    assert na == 10 or nb == 4
+def test_interleave_datasets_matches_hf_datasets_index_stream():
+    """Bit-exact against `datasets.interleave_datasets` (fixture: tests/golden/make_golden_interleave_ds.py), incl. the
+    cases that cross the library's 1000-draw batches, both stopping strategies and the probability-free cycling forms."""
+    from slamkit_amd.data.hf_dataset import interleave_indices
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "interleave_ds.json")))
+    assert len(g["cases"]) >= 9
+    for c in g["cases"]:
+        got = interleave_indices(c["lengths"], c["probabilities"], c["seed"], c["stopping_strategy"])
+        assert [list(x) for x in got] == c["order"], (c["lengths"], c["stopping_strategy"])
+    c = g["cases"][1]
+    dss = [TokenDataset([{"input_ids": [1000 * k + i], "attention_mask": [1]} for i in range(n)]) for k, n in enumerate(c["lengths"])]
+    x = interleave_datasets(dss, c["probabilities"], seed=0, stopping_strategy=c["stopping_strategy"])
+    assert [r["input_ids"][0] for r in x.rows] == [1000 * k + i for k, i in c["order"]]
+
+
+def test_wide_vocabulary_shards_use_uint32(tmp_path):
+    """Interleaved speech-text ids reach 152,166 (> 65535): the shard switches to uint32 and records it in meta.json."""
+    rows = [{"input_ids": [1, 151667, 152166, 7], "attention_mask": [1] * 4}, {"input_ids": [70000], "attention_mask": [1]}]
+    write_token_shard(str(tmp_path / "wide"), TokenDataset(rows))
+    meta = json.load(open(tmp_path / "wide" / "meta.json"))
+    assert meta["dtype"] == "uint32" and meta["tokens"] == 5
+    ds = TokenShardDataset(str(tmp_path / "wide"))
+    assert [ds[i]["input_ids"] for i in range(2)] == [r["input_ids"] for r in rows]
+    write_token_shard(str(tmp_path / "narrow"), TokenDataset([{"input_ids": [1, 65535], "attention_mask": [1, 1]}]))
+    assert json.load(open(tmp_path / "narrow" / "meta.json"))["dtype"] == "uint16"
+    assert os.path.getsize(tmp_path / "narrow" / "tokens.bin") == 4 and os.path.getsize(tmp_path / "wide" / "tokens.bin") == 20
+    write_token_shard(str(tmp_path / "wide"), TokenDataset(rows[:1]))  # overwriting replaces the directory atomically
+    assert len(TokenShardDataset(str(tmp_path / "wide"))) == 1 and not [d for d in os.listdir(tmp_path) if ".tmp" in d]
+
+
+def test_preference_dataset_repetition_filter(tmp_path):
+    """hf_dataset.py:125-148 + calculation_utils.py:32-47: auto-BLEU on prompt_text + chosen_text, then column selection."""
+    from slamkit_amd.data import init_preference_optimization_dataset
+    from slamkit_amd.data.hf_dataset import calc_auto_bleu, word_tokenize
+    assert word_tokenize("i don't know it's fine") == ["i", "do", "n't", "know", "it", "'s", "fine"]
+    assert calc_auto_bleu("a b a b c", 2) == 0.5 and calc_auto_bleu("", 2) == 0 and calc_auto_bleu("x", 2) == 0
+    rows = [dict(prompt="<Un1>", chosen="<Un2>", rejected="<Un3>", prompt_text="the cat sat", chosen_text="on the mat today", extra=1),
+            dict(prompt="<Un4>", chosen="<Un5>", rejected="<Un6>", prompt_text="go go go go", chosen_text="go go go go", extra=2)]
+    p = tmp_path / "prefs.jsonl"
+    p.write_text("\n".join(json.dumps(r) for r in rows))
+    cfg = {"train_path": str(p), "val_path": str(p), "repetition_filter": True, "auto_bleu_n": 2, "max_auto_bleu": 0.3}
+    ds = init_preference_optimization_dataset(cfg)
+    assert ds["train"] == [dict(prompt="<Un1>", chosen="<Un2>", rejected="<Un3>")] and ds["validation"] == ds["train"]
+    assert len(init_preference_optimization_dataset(dict(cfg, repetition_filter=False))["train"]) == 2
 
 
 def test_config_loader_matches_reference_hyperparameters():

@@ -1,0 +1,187 @@
+"""World-size-2 (gloo, CPU) run of the REAL SLAMTrainer step loop - token-count all-reduce, both
+`average_tokens_across_devices` modes, round-robin batch dealing, bucket callback -> GradBucketReducer, joint
+stop / evaluate / save decisions - around a stub model that implements the engine surface the trainer calls
+(forward / backward with bucket callback / grad_norm / adamw_step) with a bag-of-embeddings LM in plain torch
+(the HIP engine needs a GPU; the oracle's clip and AdamW are the stub's optimizer: test infrastructure).
+Checked: after 3 optimizer steps (GA 2) every rank holds the parameters of a single-process run over the same
+global batches, to fp32 round-off; the logged loss is the global token-mean loss."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+V, H = 37, 16
+
+
+class StubEngine:
+    def __init__(self, m):
+        self.m = m
+        self.n_params = m.flat_master.numel()
+
+    def set_option(self, key, value):
+        if key == "grad_overwrite_next":
+            self.m.overwrite = bool(value)
+
+    def join(self):
+        pass
+
+    def grad_norm(self, max_norm, norm_out):
+        from oracle import slam_oracle as O
+        n, c = O.clip_coef({"g": self.m.flat_grads}, max_norm)
+        norm_out[0], norm_out[1] = float(n), float(c)
+
+    def adamw_step(self, master, m, v, norm_out, lr, b1, b2, eps, wd, step, zero_grad=True):
+        from oracle import slam_oracle as O
+        O.adamw_update(master, self.m.flat_grads * float(norm_out[1]), m, v, step, lr, b1, b2, eps, wd)
+        if zero_grad:
+            self.m.flat_grads.zero_()
+
+
+class StubLM:
+    """logits[b,t] = E[ids[b,t]] @ W^T ; loss = compute_loss (shifted CE, sum / num_items)."""
+
+    def __init__(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.device = torch.device("cpu")
+        self.flat_master = torch.randn(V * H + V * H, generator=g) * 0.3
+        self.flat_grads = torch.zeros_like(self.flat_master)
+        self.engine = StubEngine(self)
+        self.overwrite = False
+        self.saved = []
+
+    def forward(self, input_ids=None, labels=None, num_items_in_batch=None, **kw):
+        p = self.flat_master.detach().clone().requires_grad_(True)
+        E, W = p[: V * H].view(V, H), p[V * H:].view(V, H)
+        logits = E[input_ids] @ W.t()
+        from oracle.slam_oracle import compute_loss
+        loss = compute_loss(logits, labels, num_items_in_batch=num_items_in_batch)
+        self._graph = (loss, p)
+        return type("Out", (), {"loss": loss.detach(), "logits": logits.detach()})()
+
+    def backward(self, grad_scale=1.0, bucket_layers=0, bucket_cb=None):
+        loss, p = self._graph
+        (g,) = torch.autograd.grad(loss * grad_scale, p)
+        if self.overwrite:
+            self.flat_grads.copy_(g)
+            self.overwrite = False
+        else:
+            self.flat_grads.add_(g)
+        if bucket_cb is not None:  # ranges reported back to front, like slam_backward
+            bucket_cb(V * H, V * H)
+            bucket_cb(0, V * H)
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        self.saved.append(path)
+
+
+def make_rows(n=24, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for _ in range(n):
+        k = int(torch.randint(3, 12, (1,), generator=g))
+        rows.append({"input_ids": torch.randint(1, V, (k,), generator=g).tolist(), "attention_mask": [1] * k})
+    return rows
+
+
+def run_trainer(rank, world, avg_tokens, out_dir):
+    from slamkit_amd.data import DataCollatorForLanguageModeling
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    args = SLAMTrainingArguments(output_dir=out_dir, per_device_train_batch_size=2, gradient_accumulation_steps=2,
+                                 learning_rate=1e-2, warmup_steps=1, warmup_ratio=0.0, max_steps=3, logging_steps=1,
+                                 average_tokens_across_devices=avg_tokens, ddp_bucket_layers=1, seed=5, save_steps=0)
+    model = StubLM()
+    tr = SLAMTrainer(model=model, args=args, data_collator=DataCollatorForLanguageModeling(pad_token_id=0),
+                     train_dataset=make_rows())
+    assert (tr.rank, tr.world) == (rank, world)
+    tr.train()
+    return model, tr
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for avg in (True, False):
+            model, tr = run_trainer(rank, world, avg, os.path.join(tmp, f"r{rank}"))
+            res[avg] = (model.flat_master.tolist(), [h["loss"] for h in tr.state.log_history],
+                        tr.state.num_input_tokens_seen)
+        # joint control decisions: only rank 1's clock fired -> both ranks must evaluate / save / stop
+        c = tr.control
+        c.should_training_stop = c.should_evaluate = c.should_save = (rank == 1)
+        tr._sync_control()
+        flags = (c.should_training_stop, c.should_evaluate, c.should_save)
+        c.should_training_stop = c.should_evaluate = c.should_save = False
+        tr._sync_control()
+        flags0 = (c.should_training_stop, c.should_evaluate, c.should_save)
+        q.put((rank, res, flags, flags0))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_process_reference(avg_tokens, world=2):
+    """The same 3 optimizer steps in one process: at each step the union of what the ranks see."""
+    from oracle import slam_oracle as O
+    from slamkit_amd.data import DataCollatorForLanguageModeling
+    from slamkit_amd.trainer.dp import seeded_batches, shard_batches
+    from slamkit_amd.trainer.training_args import SLAMTrainingArguments, lr_lambda
+    rows, coll = make_rows(), DataCollatorForLanguageModeling(pad_token_id=0)
+    m = StubLM()
+    a = SLAMTrainingArguments(learning_rate=1e-2, warmup_steps=1, warmup_ratio=0.0)
+    ea, eq = torch.zeros_like(m.flat_master), torch.zeros_like(m.flat_master)
+    per_rank = [shard_batches(seeded_batches(len(rows), 2, 5, 0), r, world) for r in range(world)]
+    losses, seen = [], 0
+    for step in range(3):
+        micro = [[coll([rows[i] for i in per_rank[r][2 * step + j]]) for j in range(2)] for r in range(world)]
+        counts = [sum(int((mb["labels"] != -100).sum()) for mb in micro[r]) for r in range(world)]
+        m.flat_grads.zero_()
+        tot = 0.0
+        for r in range(world):
+            for mb in micro[r]:
+                n = sum(counts) if avg_tokens else counts[r]
+                out = m.forward(input_ids=mb["input_ids"], labels=mb["labels"], num_items_in_batch=float(n))
+                m.backward(1.0 if avg_tokens else 1.0 / world)
+                tot += float(out.loss) * (1.0 if avg_tokens else 1.0 / world)
+        losses.append(tot)
+        seen += sum(counts)
+        n, c = O.clip_coef({"g": m.flat_grads}, a.max_grad_norm)
+        O.adamw_update(m.flat_master, m.flat_grads * float(c), ea, eq, step + 1, 1e-2 * lr_lambda(a, step, 3))
+    return m.flat_master, losses, seen
+
+
+def test_slam_trainer_world2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for avg in (True, False):
+        ref_p, ref_losses, ref_seen = _single_process_reference(avg)
+        for rank, r, flags, flags0 in res:
+            p, losses, seen = r[avg]
+            p = torch.tensor(p)
+            assert torch.allclose(p, ref_p, rtol=1e-5, atol=1e-6), (avg, rank, float((p - ref_p).abs().max()))
+            assert seen == ref_seen
+            assert len(losses) == 3 and all(abs(a - b) < 1e-5 for a, b in zip(losses, ref_losses)), (avg, losses, ref_losses)
+    for rank, _, flags, flags0 in res:
+        assert flags == (True, True, True) and flags0 == (False, False, False)
+    assert res[0][1][True][0] == res[1][1][True][0]  # both ranks hold the same parameters, bit for bit
