@@ -335,14 +335,8 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_tn_dma")) { gemm_set_tn_dma((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows")) { gemm_set_group_rows((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_cmode")) { gemm_set_cmode((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_persist")) { gemm_set_persist((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_n112")) { gemm_set_n112((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256x128")) { gemm_set_256x128((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256x112")) { gemm_set_256x112((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256_var")) { gemm_set_256_var((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
@@ -602,7 +596,7 @@ int slam_cast_params(SlamEngine* h, const float* master, slam_stream_t stream) {
 // ---- single-op entry points ------------------------------------------------------------------
 int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
                     int use_glds, slam_stream_t s) {
-  gemm_set_glds(use_glds);
+  gemm_set_glds(use_glds != 0);
   int r = gemm_nt((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (const bf16_t*)bias, (const bf16_t*)resid, M, N, K,
                   (hipStream_t)s);
   gemm_set_glds(1);

@@ -21,10 +21,11 @@
 // consecutive output columns of one row: four per fragment, and eight (16-byte accesses) in the
 // default NT layout, where the column tile's rows are DMA'd in the perm64 order.
 //
-// Kernels in this file: gemm_kernel (NT / NN / register-staged TN, every fused epilogue; the default),
-// gemm_tn_bal_kernel + reduce_bal_kernel (wgrad, balanced K-splitting), and the measured-but-not-default
-// variants kept selectable through slam_set_option for A/B runs: gemm_nt_persist_kernel,
-// gemm_nt_n112_kernel, gemm_nt_k32_kernel (DESIGN.md §4 lists what each one showed).
+// Kernels in this file: gemm_kernel (128x128 tiles: NT with LDS-DMA, NN / TN / ragged shapes with register staging,
+// every fused epilogue), gemm_nt_256_kernel (256x256 tiles, 8-phase schedule, for the wide-N launches),
+// gemm_tn_bal_kernel + reduce_bal_kernel (wgrad, balanced K-splitting). The variants that lost their A/B in round 1
+// (persistent blocks, 128x112 / 256x128 / 256x112 tiles, 128x128x32 tiles with deep rings, 8-wave 64x32 blocks,
+// re-keyed swizzle) were removed in round 2; DESIGN.md section 4 keeps what each one measured.
 #include <type_traits>
 
 #include "common.h"
@@ -149,25 +150,14 @@ SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* vo
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
-// Column-tile fragment assignment for 16-byte epilogue accesses: fragment fn of a wave's 64-column block
-// takes, for MFMA row i, the tile row frag_row(fn, i) = 32(fn>>1) + 8(i>>2) + 4(fn&1) + (i&3), so that the
-// fragments fn = 2q, 2q+1 of a lane (rows i = 4g..4g+3 of each) are the 8 CONSECUTIVE output columns
-// 32q + 8g .. +7 (half the store / bias / residual instructions of the 4-column layout). The tile rows stay
-// in natural order in LDS (a permuted DMA source order put rows r and r+8 into one request: same L2
-// channel for row strides of 9728 B, -12 % on the K=4864 shape); instead the chunk swizzle of the column
-// tile is keyed for this row pattern: a ds_read_b128 lane group holds rows {8a + b : a in {0,3} or {1,2}} of
-// one chunk, and key_c(r) = (2a + h) ^ [a in {1,2}] with a = (r>>3)&3, h = (r>>1)&1 gives its 16 lanes 16
-// distinct 16-byte slots.
-SLAM_DEVICE int lds_swz_key_c(int row) {
-  const int a = (row >> 3) & 3, h = (row >> 1) & 1;
-  return ((a << 1) | h) ^ ((a ^ (a >> 1)) & 1);
-}
+// Column-tile fragment assignment for 16-byte epilogue accesses: LDS row v of a 64-row block of the column tile holds
+// tile row perm64(v) (the permutation is applied to the DMA SOURCE rows; LDS layout, swizzle and fragment reads are those
+// of the natural order), so that the fragments fn = 2q, 2q+1 of a lane (MFMA rows i = 4g..4g+3 of each) are the 8
+// CONSECUTIVE output columns 32q + 8g .. +7: half the store / bias / residual instructions of the 4-column layout.
 SLAM_DEVICE int perm64(int v) {
   const int fn = v >> 4, i = v & 15;
   return ((fn >> 1) << 5) | ((i >> 2) << 3) | ((fn & 1) << 2) | (i & 3);
 }
-// CMODE 1: the same fragment assignment obtained by permuting the DMA SOURCE rows instead (LDS row v of a
-// 64-row block holds tile row perm64(v); LDS layout, swizzle and reads as in the 4-column layout)
 template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_offsets_perm(int ld, int nrows, int row0, int tid, uint32_t* voff) {
 #pragma unroll
@@ -176,18 +166,6 @@ SLAM_DEVICE void glds_offsets_perm(int ld, int nrows, int row0, int tid, uint32_
     int row = P >> 3, cs = P & 7;
     int c = cs ^ lds_swz_key(row);
     int gr = row0 + (row & ~63) + perm64(row & 63);
-    gr = gr < nrows ? gr : nrows - 1;
-    voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
-  }
-}
-template <int THREADS, int ROWS>
-SLAM_DEVICE void glds_offsets_ckey(int ld, int nrows, int row0, int tid, uint32_t* voff) {
-#pragma unroll
-  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
-    int P = i * THREADS + tid;
-    int row = P >> 3, cs = P & 7;
-    int c = cs ^ lds_swz_key_c(row);
-    int gr = row0 + row;
     gr = gr < nrows ? gr : nrows - 1;
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
@@ -220,7 +198,7 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
   }
 }
 
-// Epilogue of the 8-column layout (CMODE 1 / 2): lane (l15, g) of wave (wm, wn) holds C[m][cw + 32q .. +7] for
+// Epilogue of the 8-column layout: lane (l15, g) of wave (wm, wn) holds C[m][cw + 32q .. +7] for
 // q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout. Fused: bias, residual, RoPE, SwiGLU fwd / bwd.
 SLAM_DEVICE void epilogue8(const GemmArgs& p, const f32x4_t (&acc)[4][4], int row0, int col0, int wm, int wn, int l15, int g) {
   // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
@@ -322,22 +300,17 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p, const f32x4_t (&acc)[4][4], int ro
   }
 }
 
-// WAVES = 4: 2x2 waves of 64x64, 2 blocks/CU; WAVES = 8: 2x4 waves of 64x32, one block per CU with a
-// deeper DMA ring (same 2 waves per SIMD, more latency budget per tile).
-//             BMT = 256 (8 waves as 4x2 of 64x64): 256x128 tile, one block per CU, 33 % fewer L2->LDS bytes
-//             per flop - at ~1 PFLOP/s the 128x128 tile already pulls ~15 TB/s through the L2.
-template <bool TA, bool TB, bool F32OUT, int NSTAGE /* >0: LDS-DMA ring of NSTAGE; 0: register staging */, int WAVES = 4,
-          int BMT = 128, int CMODE = 0 /* column-tile fragment assignment: 0 = 4-column, 1 = 8-column by DMA row order, 2 = 8-column by re-keyed swizzle */>
-__global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(GemmArgs p) {
+// 4 waves as 2x2 of 64x64, two blocks per CU. GLDS: two-stage LDS-DMA ring (operands whose rows / contraction are whole
+// tiles); otherwise register staging with bounds handling (ragged shapes, NN dgrad without a transposed image).
+// PERM: 8-column epilogue layout (NT DMA form, bf16 output).
+template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool GLDS = NSTAGE > 0;
-  constexpr int THREADS = WAVES * 64;
-  constexpr int WMN = BMT / 64, WNN = WAVES / WMN;  // wave grid
-  constexpr int NF = 8 / WNN;                        // 16-column fragments per wave
-  constexpr int A_BYTES = BMT * 128, STAGE = A_BYTES + TILE_BYTES;
-  constexpr bool PERM = CMODE != 0;  // 16-byte epilogue accesses (see lds_swz_key_c)
-  static_assert(!PERM || (GLDS && !(TA && TB) && !F32OUT && NF == 4), "8-column layout: NT DMA kernel, bf16 out, 4 waves");
-  static_assert((WAVES == 4 && BMT == 128) || (WAVES == 8 && NSTAGE > 0), "8-wave blocks exist for the DMA ring only");
+  constexpr int THREADS = 256, NSTAGE = 2, BMT = BM;
+  constexpr int WNN = 2;  // wave grid 2 x 2
+  constexpr int NF = 4;   // 16-column fragments per wave
+  constexpr int A_BYTES = TILE_BYTES, STAGE = STAGE_BYTES;
+  static_assert(!PERM || (GLDS && !(TA && TB) && !F32OUT), "8-column layout: NT DMA kernel, bf16 out");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WNN, wn = wave % WNN;
@@ -382,10 +355,6 @@ __global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(G
   const int a_base = (wn * NF * 16 + l15) * 128;  // a-operand = column (B) tile
   const int b_base = (wm * 64 + l15) * 128;  // b-operand = row (A) tile
 
-  // PERM: a-operand lane (l15, g) of fragment fn reads tile row wn*64 + frag_row(fn, l15); its swizzle key
-  // depends on l15 only
-  const int kc_lane = lds_swz_key_c(((l15 >> 2) << 3) | (l15 & 3));
-  const int a_base_p = (wn * 64 + ((l15 >> 2) << 3) + (l15 & 3)) * 128;
   auto compute = [&](int s) {
     const char* At = smem + s * STAGE;
     const char* Bt = At + A_BYTES;
@@ -394,12 +363,8 @@ __global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(G
       const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
       uint4 af[NF], bf[4];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        if constexpr (CMODE == 2)
-          af[f] = *reinterpret_cast<const uint4*>(Bt + a_base_p + ((f >> 1) * 32 + (f & 1) * 4) * 128 + (((g + 4 * kk) ^ kc_lane) << 4));
-        else
-          af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
-      }
+      for (int f = 0; f < NF; ++f)
+        af[f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
 #pragma unroll
       for (int f = 0; f < 4; ++f)
         bf[f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
@@ -451,11 +416,9 @@ __global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(G
       glds_offsets_tr<THREADS, BN>(p.ldb, col0, tid, vob);
     } else {
       glds_offsets<THREADS, BMT>(p.lda, p.R, row0, tid, voa);
-      if constexpr (CMODE == 2) glds_offsets_ckey<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
-      else if constexpr (CMODE == 1) glds_offsets_perm<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      if constexpr (PERM) glds_offsets_perm<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
       else glds_offsets<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
     }
-    constexpr int PT = (BMT + BN) * 8 / THREADS;  // DMAs per lane per tile
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int t) {
       const int k0 = kbeg + t * BK;
@@ -471,18 +434,9 @@ __global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(G
     for (int s = 0; s < D; ++s)
       if (s < nk) issue(s);
     for (int t = 0; t < nk; ++t) {
-      if constexpr (NSTAGE == 1) {
-        // single stage: no prefetch inside the block; three co-resident blocks per CU overlap each other
-        __syncthreads();
-        issue(t);
-      }
-      // tile t has landed once at most min(D-1, nk-1-t) later tiles (8 DMAs each) are outstanding
-      const int rem = min(D - 1, nk - 1 - t);
-      if (D >= 3 && rem >= 2) wait_vmcnt<2 * PT>();
-      else if (D >= 2 && rem == 1) wait_vmcnt<PT>();
-      else wait_vmcnt<0>();
+      wait_vmcnt<0>();   // tile t (the only one in flight) has landed
       __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
-      if (NSTAGE > 1 && t + D < nk) issue(t + D);
+      if (t + D < nk) issue(t + D);
       if constexpr (TR) compute_tr(t % NSTAGE);
       else compute(t % NSTAGE);
     }
@@ -658,223 +612,6 @@ __global__ __launch_bounds__(WAVES * 64, NSTAGE == 1 ? 3 : 2) void gemm_kernel(G
   }
 }
 
-// ---- persistent NT kernel -----------------------------------------------------------------------------
-// Same tile, ring, fragment layout (CMODE 1) and epilogue as gemm_kernel<NT, 2 stages, 4 waves>, but the grid
-// is the 512 block slots and each block walks tiles id, id + 512, ...: a retiring block holds its LDS and
-// registers until its output stores are acknowledged and its successor then starts with a cold prologue
-// (gate|up forward: 132 us of main loops, 159 us with the output stores). Here the first K-step of the next
-// tile is DMA'd into the free ring stage during the last K-step of the current one, so the fetch latency
-// and the store drain of a tile overlap with its epilogue.
-__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  const int nk = p.Kc / BK;
-  const uint32_t lds0 = lds_addr(smem);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-
-  auto tile_of = [&](int id, int& row0, int& col0) {
-    const int xcd = id & 7, idx = id >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    const int tc_ = in / rows_here;
-    row0 = (grp * GR + in - tc_ * rows_here) * BM;
-    col0 = tc_ * BN;
-  };
-  const int s0a = ((l15 >> 1) ^ (wn * 4)) & 7;
-  const int s0b = ((l15 >> 1) ^ (wm * 4)) & 7;
-  const int a_base = (wn * 64 + l15) * 128;
-  const int b_base = (wm * 64 + l15) * 128;
-
-  int cur = blockIdx.x;
-  if (cur >= nblk) return;
-  int row0, col0;
-  tile_of(cur, row0, col0);
-  uint32_t voa[4], vob[4];
-  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
-  glds_offsets_perm<256, 128>(p.ldb, p.Cn, col0, tid, vob);
-  int sbase = 0;  // ring stage of the current tile's K-step 0
-  {
-    const uint32_t st = lds0;
-    glds_tile<256, 128>(p.A, voa, wv, st);
-    glds_tile<256, 128>(p.B, vob, wv, st + TILE_BYTES);
-  }
-  while (true) {
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int next = cur + gridDim.x;
-    int nrow0 = 0, ncol0 = 0;
-    for (int t = 0; t < nk; ++t) {
-      wait_vmcnt<0>();  // this K-step's tile has landed (and, at t == 0, the previous tile's stores are out)
-      __syncthreads();
-      const int sidx = (sbase + t) & 1;
-      // what the 8 DMA pieces of this K-step fetch: the next K-step of this tile, or (last K-step) the
-      // first K-step of the block's next tile into the stage that has just become free
-      const bf16_t* ga = p.A + (t + 1) * BK;
-      const bf16_t* gb = p.B + (t + 1) * BK;
-      if (t + 1 == nk) {
-        // (the very last K-step of the block has nothing to fetch: it re-fetches its own first K-step into
-        //  the free stage so that the loop body stays branch-free; drained before the block exits)
-        ga = p.A; gb = p.B;
-        if (next < nblk) {
-          tile_of(next, nrow0, ncol0);
-          glds_offsets<256, 128>(p.lda, p.R, nrow0, tid, voa);
-          glds_offsets_perm<256, 128>(p.ldb, p.Cn, ncol0, tid, vob);
-        }
-      }
-      const uint32_t dstA = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((sidx ^ 1) * STAGE_BYTES) + (uint32_t)wv * 1024u);
-      const char* At = smem + sidx * STAGE_BYTES;
-      const char* Bt = At + TILE_BYTES;
-      // all 16 fragment reads of the K-step first, then 8 groups of 4 MFMAs with ONE DMA piece issued
-      // between groups: the piece's issue slots sit in the shadow of the queued MFMAs instead of in front
-      // of the K-step (8 pieces back to back cost ~1k cycles before the first MFMA)
-      uint4 af[2][4], bf[2][4];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ca = ((g + 4 * kk) ^ s0a) << 4, cb = ((g + 4 * kk) ^ s0b) << 4;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) af[kk][f] = *reinterpret_cast<const uint4*>(Bt + a_base + f * 16 * 128 + (ca ^ (f << 4)));
-#pragma unroll
-        for (int f = 0; f < 4; ++f) bf[kk][f] = *reinterpret_cast<const uint4*>(At + b_base + f * 16 * 128 + (cb ^ (f << 4)));
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm) {
-#pragma unroll
-          for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[kk][fn], bf[kk][fm], acc[fm][fn]);
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            const int i = kk * 4 + fm;  // pieces 0..3: row tile, 4..7: column tile; piece = 256 rows-chunks x 16 B
-            if (i < 4) glds16_sv(ga, voa[i], dstA + (uint32_t)(i * 4096));
-            else glds16_sv(gb, vob[i - 4], dstA + (uint32_t)(TILE_BYTES + (i - 4) * 4096));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    epilogue8(p, acc, row0, col0, wm, wn, l15, g);
-    if (next >= nblk) break;
-    cur = next; row0 = nrow0; col0 = ncol0;
-    sbase = (sbase + nk) & 1;
-  }
-  wait_vmcnt<0>();  // the trailing dummy fetch must not land in a successor block's LDS
-}
-
-// ---- 128 x 112 tiles for the N = 896 projections --------------------------------------------------------
-// M 8192 x N 896 gives 448 tiles of 128 x 128 for the 512 block slots (2 per CU): a quarter of the CUs run one
-// block instead of two and the launch takes as long as a full one. 896 = 8 x 112: with 128 x 112 tiles there are
-// exactly 512. 112 columns are 7 MFMA fragments, so the four waves split the ROWS (32 each, 2 x 7 fragments per
-// wave) and every wave reads the whole column tile: 9 fragment reads per 14 MFMAs instead of 8 per 16.
-// Same LDS layout, swizzle, DMA ring and swapped MFMA roles as gemm_kernel; 4-column epilogue (bias, residual).
-__global__ __launch_bounds__(256, 2) void gemm_nt_n112_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BN2 = 112;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
-  {
-    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
-    int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tr_, tc_;
-  {
-    const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    tc_ = in / rows_here;
-    tr_ = grp * GR + in - tc_ * rows_here;
-  }
-  const int row0 = tr_ * BM, col0 = tc_ * BN2;
-  const int nk = p.Kc / BK;
-  f32x4_t acc[2][7];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const uint32_t lds0 = lds_addr(smem);
-  uint32_t voa[4], vob[4];
-  glds_offsets<256, 128>(p.lda, p.R, row0, tid, voa);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {  // column tile: rows 112..127 of the LDS image repeat row 111 (never read)
-    const int P = i * 256 + tid, row = P >> 3, c = (P & 7) ^ lds_swz_key(row);
-    const int gr = col0 + (row < BN2 ? row : BN2 - 1);
-    vob[i] = (uint32_t)(((size_t)gr * p.ldb + c * 8) * sizeof(bf16_t));
-  }
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t & 1) * STAGE_BYTES);
-    glds_tile<256, 128>(p.A + t * BK, voa, wv, st);
-    glds_tile<256, 128>(p.B + t * BK, vob, wv, st + TILE_BYTES);
-  };
-  const int ka = (l15 >> 1) & 7;  // swizzle key of row f*16 + l15 is (ka ^ f) & 7
-  if (nk > 0) issue(0);
-  for (int t = 0; t < nk; ++t) {
-    wait_vmcnt<0>();
-    __syncthreads();
-    if (t + 1 < nk) issue(t + 1);
-    const char* At = smem + (t & 1) * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4 af[7], bf[2];
-#pragma unroll
-      for (int f = 0; f < 7; ++f)
-        af[f] = *reinterpret_cast<const uint4*>(Bt + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-        bf[f] = *reinterpret_cast<const uint4*>(At + (wave * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (2 * wave + f)) & 7) << 4));
-#pragma unroll
-      for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 7; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
-    }
-  }
-  uint2 bb[7];
-  if (p.bias) {
-#pragma unroll
-    for (int fn = 0; fn < 7; ++fn) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + fn * 16 + g * 4);
-  }
-#pragma unroll
-  for (int fm = 0; fm < 2; ++fm) {
-    const int m = row0 + wave * 32 + fm * 16 + l15;
-    const bool mok = m < p.R;
-    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
-    uint2 rr[7];
-    if (p.resid) {
-#pragma unroll
-      for (int fn = 0; fn < 7; ++fn) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + fn * 16 + g * 4);
-    }
-#pragma unroll
-    for (int fn = 0; fn < 7; ++fn) {
-      f32x4_t v = acc[fm][fn];
-      if (p.bias) {
-        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
-      }
-      if (p.resid) {
-        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + fn * 16 + g * 4) = o;
-    }
-  }
-}
-
 // ---- 256 x 256 tiles, 8 waves, 8-phase schedule ------------------------------------------------------------
 // For the wide-N projections (gate|up forward, down-proj dgrad). Eight waves as 2 (rows) x 4 (columns), each
 // owning 128 x 64 of the output (acc = 128 VGPRs); one block per CU (128 KB of LDS: two K-tile buffers of four
@@ -898,7 +635,7 @@ SLAM_DEVICE void wait_ph(int which) {
 }
 SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int VAR>  // 0 = as described; measured against it: 1 = one barrier per phase, no stagger (+3 % time), 2 = no priority raise (+8 %)
+// (measured against this schedule in round 1: one barrier per phase without the stagger +3 % time, no priority raise +8 %)
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
@@ -976,9 +713,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
       for (int f = 0; f < 2; ++f)
         bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(half + offB[f] + ((((g + 4 * kk) ^ ka ^ (wc * 2 + f)) & 7) << 4));
   };
-  auto barrier_b = [&]() { if (VAR != 1) raw_barrier(); };
+  auto barrier_b = [&]() { raw_barrier(); };
   auto mma = [&](int mq, int nq) {
-    if (VAR != 2) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -986,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
         for (int fn = 0; fn < 2; ++fn)
           acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
-    if (VAR != 2) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
   auto ktile = [&](int t, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
@@ -1027,410 +764,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   issue_half(3, 0);
   wait_vmcnt<4>();
   raw_barrier();
-  if (VAR != 1 && wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
+  if (wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
   for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
   ktile(nk - 1, std::true_type{});
-  if (VAR != 1 && wr == 0) raw_barrier();  // balance the barrier count
+  if (wr == 0) raw_barrier();  // balance the barrier count
 
   epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
   epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
 }
-
-// ---- 256 x 128 tiles, 8 waves, phase schedule with a three-deep K-tile ring ---------------------------------------
-// The N = 896 projections give only 7 column tiles of 128: with 256-row tiles they are 224 blocks, one per CU on 7/8 of
-// the chip - what the staggered phase schedule of gemm_nt_256_kernel needs (two waves of ONE block per SIMD), at the
-// price of 12.5 % idle CUs. Eight waves as 4 (rows) x 2 (columns), 64 x 64 of the output each (acc = 64 VGPRs, the
-// fragment / epilogue layout of gemm_kernel). A K-tile is two phases (column halves nq = 0, 1 of every wave, 16 MFMAs
-// each); its six 8 KB pieces (A rows 64j.., j = 0..3, read only by wave row j; Bq0; Bq1) are fetched TWO K-tiles ahead
-// into a ring of three 48 KB buffers, three pieces per phase, so a piece has two K-tiles of MFMA time to land and the
-// counted vmcnt (7 / 9 outstanding) never drains.
-template <int REM>  // K-tiles after this one that still have to be fetched from here on: 2 = steady state, 1, 0
-SLAM_DEVICE void wait_p128(int phase) {
-  if (phase == 0) { if (REM == 2) wait_vmcnt<9>(); else if (REM == 1) wait_vmcnt<6>(); else wait_vmcnt<0>(); }
-  else { if (REM == 2) wait_vmcnt<7>(); else if (REM == 1) wait_vmcnt<1>(); }
-}
-__global__ __launch_bounds__(512, 1) void gemm_nt_256x128_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PC = 64 * 128;  // piece: 64 rows x 128 B
-  constexpr int KT = 6 * PC;    // K-tile buffer: A0 A1 A2 A3 Bq0 Bq1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
-  {
-    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
-    int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tr_, tc_;
-  {
-    const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    tc_ = in / rows_here;
-    tr_ = grp * GR + in - tc_ * rows_here;
-  }
-  const int row0 = tr_ * 256, col0 = tc_ * 128;
-  const int nk = p.Kc / BK;
-  const uint32_t lds0 = lds_addr(smem);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-
-  // one chunk per lane per piece: lane -> (row r of the piece, swizzled chunk)
-  const int r = tid >> 3, c = (tid & 7) ^ lds_swz_key(r);
-  const uint32_t voA = (uint32_t)(((size_t)(row0 + r) * p.lda + c * 8) * sizeof(bf16_t));  // + 64 j rows via the base
-  uint32_t voB[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-    voB[q] = (uint32_t)(((size_t)(col0 + (r >> 5) * 64 + perm64(q * 32 + (r & 31))) * p.ldb + c * 8) * sizeof(bf16_t));
-  auto issue_piece = [&](int j, int t) {  // j: 0..3 = A rows 64j.., 4 = Bq0, 5 = Bq1
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((t % 3) * KT + j * PC) + (uint32_t)wv * 1024u);
-    if (j < 4) glds16_sv(p.A + (size_t)j * 64 * p.lda + (size_t)t * BK, voA, dst);
-    else glds16_sv(p.B + (size_t)t * BK, voB[j - 4], dst);
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int ka = (l15 >> 1) & 7;
-  uint4 afr[2][4], bfr[2][2][2];
-  auto read_A = [&](const char* buf) {
-    const char* pa = buf + wm * PC;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        afr[kk][f] = *reinterpret_cast<const uint4*>(pa + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
-  };
-  auto read_B = [&](const char* buf, int nq) {
-    const char* pb = buf + (4 + nq) * PC;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(pb + (wn * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (wn * 2 + f)) & 7) << 4));
-  };
-  auto mma = [&](int nq) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn) acc[fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[fm][nq * 2 + fn]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto ktile = [&](int t, auto rem_tag) {
-    constexpr int REM = decltype(rem_tag)::value;
-    const char* buf = smem + (t % 3) * KT;
-    // phase 1: column half 0
-    if (REM == 2) { issue_piece(0, t + 2); issue_piece(1, t + 2); issue_piece(2, t + 2); }
-    read_A(buf);
-    read_B(buf, 0);
-    wait_p128<REM>(0);  // Bq1(t) landed -> read in phase 2
-    raw_barrier();
-    mma(0);
-    raw_barrier();
-    // phase 2: column half 1
-    if (REM == 2) { issue_piece(3, t + 2); issue_piece(4, t + 2); issue_piece(5, t + 2); }
-    read_B(buf, 1);
-    wait_p128<REM>(1);  // A and Bq0 of K-tile t+1 landed -> read in its phase 1
-    raw_barrier();
-    mma(1);
-    raw_barrier();
-  };
-#pragma unroll
-  for (int j = 0; j < 6; ++j) issue_piece(j, 0);
-#pragma unroll
-  for (int j = 0; j < 6; ++j) issue_piece(j, 1);
-  wait_vmcnt<7>();
-  raw_barrier();
-  if (wave >= 4) raw_barrier();  // waves 4..7 (the second wave of every SIMD): one barrier behind
-  for (int t = 0; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 2>{});
-  ktile(nk - 2, std::integral_constant<int, 1>{});
-  ktile(nk - 1, std::integral_constant<int, 0>{});
-  if (wave < 4) raw_barrier();
-  epilogue8(p, acc, row0, col0, wm, wn, l15, g);
-}
-
-// ---- 256 x 112 tiles for the long-contraction N = 896 launches ----------------------------------------------------
-// 8192 x 896 outputs are exactly 256 tiles of 256 x 112: one block per CU on EVERY CU (256 x 128 tiles leave 32 CUs
-// idle, 128 x 128 tiles a quarter of the block slots). 112 columns = 7 MFMA fragments, split 4 + 3 between the two
-// wave columns; waves 0-3 (wave rows 0..3, 64 x 64 of the output) and waves 4-7 (64 x 48) share the SIMDs pairwise,
-// so every SIMD carries 32 + 24 MFMAs per K-tile. Otherwise gemm_nt_256x128_kernel: three-deep K-tile ring of six
-// 8 KB pieces, two phases per K-tile, second wave group one barrier behind, counted vmcnt. Four-column epilogue
-// (bias, residual): the outputs of these launches are small (14.7 MB), their contractions long.
-__global__ __launch_bounds__(512, 1) void gemm_nt_256x112_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PC = 64 * 128, KT = 6 * PC, BN2 = 112;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 2, wm = wave & 3;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
-  {
-    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
-    int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tr_, tc_;
-  {
-    const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    tc_ = in / rows_here;
-    tr_ = grp * GR + in - tc_ * rows_here;
-  }
-  const int row0 = tr_ * 256, col0 = tc_ * BN2;
-  const int nk = p.Kc / BK;
-  const uint32_t lds0 = lds_addr(smem);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int r = tid >> 3, c = (tid & 7) ^ lds_swz_key(r);
-  const uint32_t voA = (uint32_t)(((size_t)(row0 + r) * p.lda + c * 8) * sizeof(bf16_t));
-  uint32_t voB[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {  // piece q: rows 0..31 = columns 32q.. of wave column 0, rows 32..63 = of wave column 1
-    int col = (r >> 5) * 64 + q * 32 + (r & 31);
-    col = col < BN2 ? col : BN2 - 1;  // wave column 1 has 48 columns: the tail rows repeat column 111 (never used)
-    voB[q] = (uint32_t)(((size_t)(col0 + col) * p.ldb + c * 8) * sizeof(bf16_t));
-  }
-  auto issue_piece = [&](int j, int t) {
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((t % 3) * KT + j * PC) + (uint32_t)wv * 1024u);
-    if (j < 4) glds16_sv(p.A + (size_t)j * 64 * p.lda + (size_t)t * BK, voA, dst);
-    else glds16_sv(p.B + (size_t)t * BK, voB[j - 4], dst);
-  };
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int ka = (l15 >> 1) & 7;
-  uint4 afr[2][4], bfr[2][2][2];
-  auto read_A = [&](const char* buf) {
-    const char* pa = buf + wm * PC;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        afr[kk][f] = *reinterpret_cast<const uint4*>(pa + (f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ f) & 7) << 4));
-  };
-  auto read_B = [&](const char* buf, int nq) {
-    const char* pb = buf + (4 + nq) * PC;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(pb + (wn * 32 + f * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ (wn * 2 + f)) & 7) << 4));
-  };
-  auto mma = [&](int nq, auto nfn_tag) {
-    constexpr int NFN = decltype(nfn_tag)::value;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < NFN; ++fn) acc[fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[fm][nq * 2 + fn]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto ktile = [&](int t, auto rem_tag) {
-    constexpr int REM = decltype(rem_tag)::value;
-    const char* buf = smem + (t % 3) * KT;
-    if (REM == 2) { issue_piece(0, t + 2); issue_piece(1, t + 2); issue_piece(2, t + 2); }
-    read_A(buf);
-    read_B(buf, 0);
-    wait_p128<REM>(0);
-    raw_barrier();
-    mma(0, std::integral_constant<int, 2>{});
-    raw_barrier();
-    if (REM == 2) { issue_piece(3, t + 2); issue_piece(4, t + 2); issue_piece(5, t + 2); }
-    read_B(buf, 1);
-    wait_p128<REM>(1);
-    raw_barrier();
-    if (wn == 0) mma(1, std::integral_constant<int, 2>{});
-    else mma(1, std::integral_constant<int, 1>{});
-    raw_barrier();
-  };
-#pragma unroll
-  for (int j = 0; j < 6; ++j) issue_piece(j, 0);
-#pragma unroll
-  for (int j = 0; j < 6; ++j) issue_piece(j, 1);
-  wait_vmcnt<7>();
-  raw_barrier();
-  if (wave >= 4) raw_barrier();
-  for (int t = 0; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 2>{});
-  ktile(nk - 2, std::integral_constant<int, 1>{});
-  ktile(nk - 1, std::integral_constant<int, 0>{});
-  if (wave < 4) raw_barrier();
-
-  const int nfr = wn ? 3 : 4;
-  uint2 bb[4];
-  if (p.bias) {
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn)
-      if (fn < nfr) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + wn * 64 + fn * 16 + g * 4);
-  }
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int m = row0 + wm * 64 + fm * 16 + l15;
-    const size_t rowoff = (size_t)m * p.ldc;
-    uint2 rr[4];
-    if (p.resid) {
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn)
-        if (fn < nfr) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wn * 64 + fn * 16 + g * 4);
-    }
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      if (fn >= nfr) continue;
-      f32x4_t v = acc[fm][fn];
-      if (p.bias) {
-        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
-      }
-      if (p.resid) {
-        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + wn * 64 + fn * 16 + g * 4) = o;
-    }
-  }
-}
-
-// ---- experimental: 128x128x32 tiles (16 KB per stage) so that a 4/5-deep DMA ring still leaves two
-//      blocks per CU: the same two independent waves per SIMD as the 2-stage 128x128x64 kernel, with
-//      3-4 tiles of fetch latency budget instead of 1. Rows are 64 B (four 16-byte chunks), chunk
-//      swizzle key4(row) = (-(row>>2)) & 3 (conflict-free for the 16-row ds_read_b128 fragments).
-SLAM_DEVICE int key4(int row) { return (0 - (row >> 2)) & 3; }
-template <int NSTAGE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_k32_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK2 = 32, TILE2 = 128 * 64, STAGE2 = 2 * TILE2, D = NSTAGE - 1, PT = 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
-  {
-    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
-    int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tr_, tc_;
-  {
-    const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    tc_ = in / rows_here;
-    tr_ = grp * GR + in - tc_ * rows_here;
-  }
-  const int row0 = tr_ * BM, col0 = tc_ * BN;
-  const int nk = p.Kc / BK2;
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // row = w*64 + f*16 + l15 -> key4 depends on l15 only
-  const int chunk = (g ^ key4(l15)) << 4;
-  const int a_off = (wn * 64 + l15) * 64 + chunk;
-  const int b_off = (wm * 64 + l15) * 64 + chunk;
-  auto compute = [&](int s) {
-    const char* At = smem + s * STAGE2;
-    const char* Bt = At + TILE2;
-    uint4 af[4], bf[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) af[f] = *reinterpret_cast<const uint4*>(Bt + a_off + f * 16 * 64);
-#pragma unroll
-    for (int f = 0; f < 4; ++f) bf[f] = *reinterpret_cast<const uint4*>(At + b_off + f * 16 * 64);
-#pragma unroll
-    for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = mfma16(af[fn], bf[fm], acc[fm][fn]);
-  };
-  const uint32_t lds0 = lds_addr(smem);
-  uint32_t voa[2], vob[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int P = i * 256 + tid, row = P >> 2, c = (P & 3) ^ key4(row);
-    int ra = row0 + row, rb = col0 + row;
-    ra = ra < p.R ? ra : p.R - 1;
-    rb = rb < p.Cn ? rb : p.Cn - 1;
-    voa[i] = (uint32_t)(((size_t)ra * p.lda + c * 8) * sizeof(bf16_t));
-    vob[i] = (uint32_t)(((size_t)rb * p.ldb + c * 8) * sizeof(bf16_t));
-  }
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE2);
-    const bf16_t* ga = p.A + t * BK2;
-    const bf16_t* gb = p.B + t * BK2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16_sv(ga, voa[i], __builtin_amdgcn_readfirstlane(st + (uint32_t)(i * 256 + wv * 64) * 16u));
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16_sv(gb, vob[i], __builtin_amdgcn_readfirstlane(st + TILE2 + (uint32_t)(i * 256 + wv * 64) * 16u));
-  };
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < nk) issue(s);
-  for (int t = 0; t < nk; ++t) {
-    const int rem = min(D - 1, nk - 1 - t);
-    switch (rem) {
-      case 0: wait_vmcnt<0>(); break;
-      case 1: wait_vmcnt<PT>(); break;
-      case 2: wait_vmcnt<2 * PT>(); break;
-      case 3: wait_vmcnt<3 * PT>(); break;
-      default: wait_vmcnt<4 * PT>(); break;
-    }
-    __syncthreads();
-    if (t + D < nk) issue(t + D);
-    compute(t % NSTAGE);
-  }
-  uint2 bb[4];
-  if (p.bias) {
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) bb[fn] = *reinterpret_cast<const uint2*>(p.bias + col0 + wn * 64 + fn * 16 + g * 4);
-  }
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int m = row0 + wm * 64 + fm * 16 + l15;
-    const bool mok = m < p.R;
-    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
-    uint2 rr[4];
-    if (p.resid) {
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn) rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wn * 64 + fn * 16 + g * 4);
-    }
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      const int n = col0 + wn * 64 + fn * 16 + g * 4;
-      f32x4_t v = acc[fm][fn];
-      if (p.bias) {
-        v[0] += __uint_as_float(bb[fn].x << 16); v[1] += __uint_as_float(bb[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(bb[fn].y << 16); v[3] += __uint_as_float(bb[fn].y & 0xffff0000u);
-      }
-      if (p.resid) {
-        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      if (mok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + n) = o;
-    }
-  }
-}
-template <int NSTAGE>
-int launch_k32(GemmArgs a, hipStream_t st);
 
 // ---- wgrad with balanced K-splitting ----------------------------------------------------------------
 // dW[R][Cn] (fp32) (+)= A^T B with A [Kc][R], B [Kc][Cn] (both stored contraction-major), for the
@@ -1608,36 +949,21 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
 static int g_nt_store = 0;
 static int g_group_rows = 3;  // step-level A/B on MI355X (same box): 1 -> 32.4 ms, 2 -> 31.2, 3 -> 31.2, 4 -> 31.5, 8 -> 32.8
 
-template <bool TA, bool TB, bool F32OUT, int NSTAGE, int WAVES = 4, int BMT = 128, int CMODE = 0>
+template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false>
 int launch(GemmArgs a, int splits, hipStream_t st) {
-  constexpr int lds = (NSTAGE > 0 ? NSTAGE : 2) * (BMT * 128 + TILE_BYTES);
+  constexpr int lds = 2 * STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT, CMODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, GLDS, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  a.tiles_r = (a.R + BMT - 1) / BMT;
+  a.tiles_r = (a.R + BM - 1) / BM;
   a.group_rows = g_group_rows;
   a.nt_store = g_nt_store;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, NSTAGE, WAVES, BMT, CMODE><<<grid, WAVES * 64, lds, st>>>(a);
-  return (int)hipGetLastError();
-}
-
-template <int NSTAGE>
-int launch_k32(GemmArgs a, hipStream_t st) {
-  constexpr int lds = NSTAGE * 2 * 128 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k32_kernel<NSTAGE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  a.group_rows = g_group_rows;
-  gemm_nt_k32_kernel<NSTAGE><<<a.tiles_r * a.tiles_c, 256, lds, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, GLDS, PERM><<<grid, 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -1645,11 +971,9 @@ int launch_k32(GemmArgs a, hipStream_t st) {
 
 namespace slam {
 
-// gemm_glds: 0 = register staging, 2/3/4 = LDS-DMA ring depth
-static int g_gemm_glds = 2;
-static int g_gemm_cmode = 1;
-void gemm_set_cmode(int m) { g_gemm_cmode = m; }
-// the default NT kernel (2-stage ring, 4 waves) in the selected column-tile layout
+// gemm_glds: 1 = LDS-DMA staging where the shape allows (default), 0 = register staging everywhere (parity tests)
+static int g_gemm_glds = 1;
+// gemm_256: 1 = the 256 x 256 kernel when its fill criterion holds (default), 0 = never, 2 = whenever the shape allows (tests)
 static int g_gemm_256 = 1;
 void gemm_set_256(int on) { g_gemm_256 = on; }
 // the 256 x 256 kernel runs one block per CU: worth it when the tiles fill most of whole rounds of the 256 CUs
@@ -1662,16 +986,12 @@ static bool use_256(const GemmArgs& a) {
   if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
   return tiles >= 256 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.74;
 }
-static int g_256_var = 0;
 static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
 void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
-void gemm_set_256_var(int v) { g_256_var = v; }
 static int launch_256(GemmArgs a, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
@@ -1679,110 +999,16 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.tiles_c = a.Cn / 256;
   a.group_rows = g_group_rows_256;
   a.nt_store = g_nt_store;
-  if (g_256_var == 1) gemm_nt_256_kernel<1><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
-  else if (g_256_var == 2) gemm_nt_256_kernel<2><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
-  else gemm_nt_256_kernel<0><<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
-static int g_gemm_256x128 = 0;  // measured equal-to-slower than 448 tiles of 128 x 128 (gate|up dgrad 143.7 vs 138.9 us): selectable
-void gemm_set_256x128(int on) { g_gemm_256x128 = on; }
-static bool use_256x128(const GemmArgs& a) {
-  if (!g_gemm_256x128 || (a.R % 256) || (a.Cn % 128) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
-  const int tiles = (a.R / 256) * (a.Cn / 128);
-  if (g_gemm_256x128 == 2) return true;  // forced (tests / A-B)
-  return tiles <= 256 && tiles >= 216 && a.Kc >= 2048;  // one round on >= 85 % of the CUs, long contraction
-}
-static int launch_256x128(GemmArgs a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256x128_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 6 * 64 * 128);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  a.tiles_r = a.R / 256;
-  a.tiles_c = a.Cn / 128;
-  a.group_rows = g_group_rows_256;
-  a.nt_store = g_nt_store;
-  gemm_nt_256x128_kernel<<<a.tiles_r * a.tiles_c, 512, 3 * 6 * 64 * 128, st>>>(a);
-  return (int)hipGetLastError();
-}
-static int g_gemm_256x112 = 0;  // measured: full fill of the CUs but 976 vs 1040 TFLOP/s on the gate|up dgrad: selectable only
-void gemm_set_256x112(int on) { g_gemm_256x112 = on; }
-static bool use_256x112(const GemmArgs& a) {
-  if (!g_gemm_256x112 || (a.R % 256) || (a.Cn % 112) || (a.Kc % BK) || a.Kc < 2 * BK || a.act || a.gu || a.rope_cos) return false;
-  if (g_gemm_256x112 == 2) return true;  // forced (tests / A-B)
-  const int tiles = (a.R / 256) * (a.Cn / 112);
-  return tiles >= 224 && tiles <= 256 && a.Kc >= 2048;
-}
-static int launch_256x112(GemmArgs a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256x112_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 6 * 64 * 128);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  a.tiles_r = a.R / 256;
-  a.tiles_c = a.Cn / 112;
-  a.group_rows = g_group_rows_256;
-  gemm_nt_256x112_kernel<<<a.tiles_r * a.tiles_c, 512, 3 * 6 * 64 * 128, st>>>(a);
-  return (int)hipGetLastError();
-}
-static int g_gemm_n112 = 0;  // measured: bit-identical results, but 5-10 % slower than 448 tiles of 128 x 128 (o fwd 20.0 vs 18.1 us, gate|up dgrad 147.6 vs 139.3)
-void gemm_set_n112(int on) { g_gemm_n112 = on; }
-// 128 x 112 tiles when they fill the 512 block slots better than 128 x 128 ones (N = 896: 512 vs 448 tiles)
-static bool use_n112(const GemmArgs& a) {
-  if (!g_gemm_n112 || a.Cn % 112 || a.act || a.gu || a.rope_cos) return false;
-  const int tr = (a.R + BM - 1) / BM;
-  auto fill = [](int tiles) { return (double)tiles / (double)(((tiles + 511) / 512) * 512); };
-  return fill(tr * (a.Cn / 112)) > fill(tr * (a.Cn / BN)) + 0.05;
-}
-static int launch_n112(GemmArgs a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_n112_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  a.tiles_r = (a.R + BM - 1) / BM;
-  a.tiles_c = a.Cn / 112;
-  a.group_rows = g_group_rows;
-  gemm_nt_n112_kernel<<<a.tiles_r * a.tiles_c, 256, 2 * STAGE_BYTES, st>>>(a);
-  return (int)hipGetLastError();
-}
-static int g_gemm_persist = 0;  // measured neutral at kernel and step level (30.26 vs 30.20 ms): kept selectable ("gemm_persist")
-void gemm_set_persist(int on) { g_gemm_persist = on; }
-static int launch_nt2(const GemmArgs& a0, hipStream_t st) {
-  if (g_gemm_persist && g_gemm_cmode == 1 && a0.tiles_r * a0.tiles_c > 512) {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_persist_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-      if (e != hipSuccess) return (int)e;
-      attr = true;
-    }
-    GemmArgs a = a0;
-    a.tiles_r = (a.R + BM - 1) / BM;
-    a.group_rows = g_group_rows;
-    a.nt_store = g_nt_store;
-    gemm_nt_persist_kernel<<<512, 256, 2 * STAGE_BYTES, st>>>(a);
-    return (int)hipGetLastError();
-  }
-  if (use_n112(a0)) return launch_n112(a0, st);
-  if (g_gemm_cmode == 1 && use_256(a0)) return launch_256(a0, st);
-  if (g_gemm_cmode == 1 && use_256x128(a0)) return launch_256x128(a0, st);
-  if (use_256x112(a0)) return launch_256x112(a0, st);
-  const GemmArgs& a = a0;
-  switch (g_gemm_cmode) {
-    case 1: return launch<false, false, false, 2, 4, 128, 1>(a, 1, st);
-    case 2: return launch<false, false, false, 2, 4, 128, 2>(a, 1, st);
-    default: return launch<false, false, false, 2>(a, 1, st);
-  }
+// NT launches whose rows / contraction are whole tiles: 256 x 256 8-phase kernel or the 128 x 128 DMA kernel
+static int launch_nt_dma(const GemmArgs& a, hipStream_t st) {
+  if (use_256(a)) return launch_256(a, st);
+  return launch<false, false, false, true, true>(a, 1, st);
 }
 static int g_gemm_tn_dma = 1;
-void gemm_set_glds(int mode) { g_gemm_glds = (mode == 1) ? 2 : mode; }
+void gemm_set_glds(int mode) { g_gemm_glds = mode; }
 void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
 void gemm_set_group_rows(int g) { g_group_rows = g; }
 void gemm_set_nt_store(int on) { g_nt_store = on; }
@@ -1800,22 +1026,8 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   GemmArgs a{X, W, Y, bias, resid, nullptr, nullptr, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (N + BN - 1) / BN};
   const bool dma_ok = (K % BK == 0) && (N % BN == 0);
-  const int mode = dma_ok ? g_gemm_glds : 0;
-  switch (mode) {
-    case 2: return launch_nt2(a, st);
-    case 11: return launch<false, false, false, 1, 4, 128, 1>(a, 1, st);
-    case 3: return launch<false, false, false, 3>(a, 1, st);
-    case 4: return launch<false, false, false, 4>(a, 1, st);
-    case 323: return launch_k32<3>(a, st);
-    case 324: return launch_k32<4>(a, st);
-    case 325: return launch_k32<5>(a, st);
-    case 82: return launch<false, false, false, 2, 8>(a, 1, st);
-    case 162: return launch<false, false, false, 2, 8, 256>(a, 1, st);
-    case 163: return launch<false, false, false, 3, 8, 256>(a, 1, st);
-    case 83: return launch<false, false, false, 3, 8>(a, 1, st);
-    case 84: return launch<false, false, false, 4, 8>(a, 1, st);
-    default: return launch<false, false, false, 0>(a, 1, st);
-  }
+  if (dma_ok && g_gemm_glds) return launch_nt_dma(a, st);
+  return launch<false, false, false, false>(a, 1, st);
 }
 
 // QKV projection with bias and rotate-half RoPE applied to the first rope_heads heads in the epilogue
@@ -1823,16 +1035,13 @@ int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias
                  int rope_heads, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN, cs, sn, rope_heads};
-  return launch_nt2(a, st);
+  return launch_nt_dma(a, st);
 }
 
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, nullptr, nullptr, act, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  // (the 256x128 / 3-stage variant, mode 163, was +16 % here before the grouped tile order; with it the
-  //  128x128 kernel is faster again: 866 vs 782 TFLOP/s at M 8192, N 9728, K 896)
-  if (g_gemm_glds == 163) return launch<false, false, false, 3, 8, 256>(a, 1, st);
-  return launch_nt2(a, st);
+  return launch_nt_dma(a, st);
 }
 
 // d(act)[M,N] = dY[M,K] Wt[N,K]^T is never stored: gu [M,2N] (32-column gate/up blocks) is rewritten in
@@ -1840,7 +1049,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
   GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  return launch_nt2(a, st);
+  return launch_nt_dma(a, st);
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+resid[M,K]); contraction over N.
@@ -1849,7 +1058,7 @@ int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, 
   if (check_dims(M, K, N, N, K, K) || (N & 7)) return -1;
   GemmArgs a{dY, W, dX, nullptr, resid, nullptr, nullptr, M, K, N, N, K, K, ((N + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (K + BN - 1) / BN};
-  return launch<false, true, false, 0>(a, 1, st);
+  return launch<false, true, false, false>(a, 1, st);
 }
 
 static int g_tn_splits_override = 0;
@@ -1950,10 +1159,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   splits = (M + per - 1) / per;
   GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
   const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
-  int e;
-  if (dma_ok && g_gemm_tn_dma == 2 && N % 256 == 0) e = launch<true, true, true, 2, 8, 256>(a, splits, st);
-  else if (dma_ok && g_gemm_tn_dma == 3 && N % 256 == 0) e = launch<true, true, true, 3, 8, 256>(a, splits, st);
-  else e = dma_ok ? launch<true, true, true, 2>(a, splits, st) : launch<true, true, true, 0>(a, splits, st);
+  int e = dma_ok ? launch<true, true, true, true>(a, splits, st) : launch<true, true, true, false>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
   reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate);

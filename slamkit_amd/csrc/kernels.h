@@ -13,14 +13,8 @@ void gemm_set_glds(int on);
 void gemm_set_tn_dma(int on);
 void gemm_set_tn_splits(int s);
 void gemm_set_group_rows(int g);
-void gemm_set_cmode(int m);
 void gemm_set_nt_store(int on);
-void gemm_set_persist(int on);
-void gemm_set_n112(int on);
 void gemm_set_256(int on);
-void gemm_set_256x128(int on);
-void gemm_set_256x112(int on);
-void gemm_set_256_var(int v);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,

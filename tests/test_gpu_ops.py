@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("glds", [0, 1, 3, 4, 323, 325, 83, 84, 162, 163])
+@pytest.mark.parametrize("glds", [0, 1])  # register staging / LDS-DMA
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 256, 128), (1000, 1152, 896),
                                    (74, 512, 256)])
 def test_gemm_nt(M, N, K, glds):
@@ -29,23 +29,6 @@ def test_gemm_nt(M, N, K, glds):
         assert rc == 0
         ref = X @ W.t() + (bias if use_bias else 0) + (res if use_res else 0)
         check(f"gemm_nt {M}x{N}x{K} glds={glds} epi={use_bias}", Y.float(), ref, 4e-3, 2e-2)
-
-
-@pytest.mark.parametrize("M,N,K", [(3072, 3072, 128), (2000, 4224, 192)])
-def test_gemm_nt_persistent_variant(M, N, K):
-    """The selectable persistent kernel (512 block slots walking > 512 tiles, cross-tile prefetch) gives the same bits."""
-    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
-    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
-    outs = []
-    for persist in (0, 1):
-        assert lib().slam_set_option(None, b"gemm_persist", persist) == 0
-        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
-        sync()
-        outs.append(Y)
-    lib().slam_set_option(None, b"gemm_persist", 0)
-    check("gemm_nt persistent", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
-    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 128), (2048, 8192, 192), (4096, 2048, 64 * 5)])
@@ -74,59 +57,6 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     check("gemm 256 plain", outs[2][1].float(), ref, 4e-3, 2e-2)
     gu = ref.view(M, N // 64, 2, 32)
     check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
-
-
-@pytest.mark.parametrize("M,N,K", [(1024, 896, 64 * 5), (2048, 384, 64 * 2), (512, 128, 64 * 9)])
-def test_gemm_nt_256x128_variant(M, N, K):
-    """The selectable 256 x 128 kernel (three-deep K-tile ring, staggered wave groups): same bits as the default,
-    for K-tile counts that exercise the 2-, 3- and many-tile paths of its tail handling."""
-    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
-    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
-    outs = []
-    for on in (0, 2):
-        assert lib().slam_set_option(None, b"gemm_256x128", on) == 0
-        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
-        sync()
-        outs.append(Y)
-    lib().slam_set_option(None, b"gemm_256x128", 0)
-    check("gemm_nt 256x128", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
-    assert torch.equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("M,N,K", [(1024, 896, 64 * 5), (512, 896, 64 * 2), (256, 1792, 64 * 7)])
-def test_gemm_nt_256x112_variant(M, N, K):
-    """The selectable 256 x 112 kernel (4 + 3 fragment split between the wave columns): same bits as the default."""
-    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
-    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
-    outs = []
-    for on in (0, 2):
-        assert lib().slam_set_option(None, b"gemm_256x112", on) == 0
-        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        rc = lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream())
-        sync()
-        assert rc == 0
-        outs.append(Y)
-    lib().slam_set_option(None, b"gemm_256x112", 0)
-    check("gemm_nt 256x112", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
-    assert torch.equal(outs[0], outs[1])
-
-
-def test_gemm_nt_n112_variant():
-    """The selectable 128 x 112 tiling (N = 896 -> exactly 512 tiles at M = 8192) gives the same bits as the default."""
-    M, N, K = 1100, 896, 256
-    X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
-    Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
-    outs = []
-    for on in (0, 1):
-        assert lib().slam_set_option(None, b"gemm_n112", on) == 0
-        Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), ptr(bd), ptr(rd), M, N, K, 2, stream()) == 0
-        sync()
-        outs.append(Y)
-    lib().slam_set_option(None, b"gemm_n112", 0)
-    check("gemm_nt n112", outs[1].float(), X @ W.t() + bias + res, 4e-3, 2e-2)
-    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 192, 384), (300, 512, 256), (1000, 1152, 896),
