@@ -123,6 +123,13 @@ int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t
 int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp_avg_sq, const float* norm_out,
                     double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
                     int32_t zero_grad, slam_stream_t stream);
+/* The Slam recipe's own optimizer precision (/root/reference config/model/slam.yaml:9 `torch_dtype: bfloat16`: bf16
+ * parameters and bf16 Adam moments, torch.optim.AdamW(fused) semantics: fp32 arithmetic per element from the stored bf16
+ * values, one rounding on the way back, no fp32 master copy). Updates the BOUND bf16 parameter buffer in place and
+ * refreshes the transposed images; exp_avg / exp_avg_sq: bf16 [slam_param_count]. 16 B/param instead of 30. */
+int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t zero_grad,
+                         slam_stream_t stream);
 /* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
  * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
  * joins first. slam_join makes `stream` wait for a pending update before the caller touches the parameter, gradient or

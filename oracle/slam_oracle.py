@@ -366,6 +366,29 @@ def adamw_update(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def adamw_update_bf16(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    """torch.optim.AdamW(fused=True) on bf16 parameters with bf16 moments, in place - the optimizer precision of the
+    Slam recipe (/root/reference config/model/slam.yaml:9 `torch_dtype: bfloat16`; the HF Trainer builds AdamW on the
+    bf16 parameters, so exp_avg / exp_avg_sq are bf16 too). Restated from the fused kernel's semantics: every element
+    is widened to fp32, exp_avg moves by lerp(exp_avg, g, 1 - b1), exp_avg_sq = b2 v + (1 - b2) g^2, the parameter step
+    uses lr / (1 - b1^t) and sqrt(v) / sqrt(1 - b2^t) + eps, and each tensor is rounded to bf16 once when stored.
+    `g` may be fp32 (the engine keeps fp32 gradients) or bf16. Pinned against torch's own fused CPU kernel by
+    tests/test_oracle_golden.py::test_adamw_bf16_state_matches_torch_fused."""
+    assert p.dtype == m.dtype == v.dtype == torch.bfloat16
+    f = torch.float32
+    pf, mf, vf, gf = p.to(f), m.to(f), v.to(f), g.to(f)
+    pf = pf * torch.tensor(1 - lr * wd, dtype=f)
+    mf = mf + torch.tensor(1 - b1, dtype=f) * (gf - mf)
+    vf = torch.tensor(b2, dtype=f) * vf + torch.tensor(1 - b2, dtype=f) * gf * gf
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    den = vf.sqrt() / torch.tensor(math.sqrt(bc2), dtype=f) + torch.tensor(eps, dtype=f)
+    pf = pf - torch.tensor(lr / bc1, dtype=f) * (mf / den)
+    p.copy_(pf.to(torch.bfloat16))
+    m.copy_(mf.to(torch.bfloat16))
+    v.copy_(vf.to(torch.bfloat16))
+
+
 def dpo_loss(pi_c, pi_r, ref_c, ref_r, beta=0.1):
     """Sigmoid DPO loss from its definition (TRL absent here - parity unpinned)."""
     return -F.logsigmoid(beta * ((pi_c - pi_r) - (ref_c - ref_r))).mean()

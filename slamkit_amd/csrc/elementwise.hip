@@ -713,6 +713,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_
   if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
 }
 
+// The Slam recipe's optimizer precision (/root/reference config/model/slam.yaml:9 torch_dtype bfloat16 -> bf16 parameters
+// and bf16 Adam moments under torch.optim.AdamW(fused=True)): state is STORED in bf16, every update is computed in fp32
+// from the stored values and rounded once on the way back (torch's fused kernel: opmath fp32, exp_avg by lerp).
+// No fp32 master copy. Traffic: fp32 g read (4) + bf16 p, m, v read and written (12) = 16 B/param.
+__global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p, float* __restrict__ g,
+                                                         bf16_t* __restrict__ m, bf16_t* __restrict__ v, size_t n,
+                                                         const float* __restrict__ clip, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  const float cs = clip ? clip[1] : 1.f;
+  float4 g0 = *reinterpret_cast<float4*>(g + i), g1 = *reinterpret_cast<float4*>(g + i + 4);
+  float ga[8] = {g0.x * cs, g0.y * cs, g0.z * cs, g0.w * cs, g1.x * cs, g1.y * cs, g1.z * cs, g1.w * cs};
+  float pa[8], ma[8], va[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(p + i), pa);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(m + i), ma);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(v + i), va);
+  const float step = lr / bc1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pa[j] *= (1.f - lr * wd);
+    ma[j] = ma[j] + (1.f - b1) * (ga[j] - ma[j]);
+    va[j] = b2 * va[j] + (1.f - b2) * ga[j] * ga[j];
+    const float den = sqrtf(va[j]) / bc2_sqrt + eps;
+    pa[j] -= step * (ma[j] / den);
+  }
+  *reinterpret_cast<uint4*>(p + i) = pack_bf16x8(pa);
+  *reinterpret_cast<uint4*>(m + i) = pack_bf16x8(ma);
+  *reinterpret_cast<uint4*>(v + i) = pack_bf16x8(va);
+  if (zero_grad) {
+    *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
+    *reinterpret_cast<float4*>(g + i + 4) = make_float4(0, 0, 0, 0);
+  }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
@@ -901,6 +936,15 @@ int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const fl
   float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
   adamw_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
                                                      (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  LAUNCH_RET();
+}
+int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
+               double eps, double wd, int step, int zero_grad, hipStream_t st) {
+  if (n & 7) return -1;
+  float bc1 = (float)(1.0 - pow(b1, (double)step));
+  float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
+  adamw_bf16_kernel<<<nblocks(n / 8, 256), 256, 0, st>>>(p, g, m, v, n, clip, (float)lr, (float)b1, (float)b2, (float)eps,
+                                                         (float)wd, bc1, bc2s, zero_grad);
   LAUNCH_RET();
 }
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st) {

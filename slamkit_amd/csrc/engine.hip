@@ -573,6 +573,18 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
   return SLAM_OK;
 }
 
+int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out, double lr,
+                         double b1, double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
+  if (!h || !exp_avg_bf16 || !exp_avg_sq_bf16 || step < 1) return SLAM_EINVAL;
+  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  if (h->n_params & 7) return h->fail(SLAM_EINVAL, "parameter count must be a multiple of 8");
+  hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
+  CK(adamw_bf16(h->params, h->grads, (bf16_t*)exp_avg_bf16, (bf16_t*)exp_avg_sq_bf16, (size_t)h->n_params, norm_out, lr, b1,
+                b2, eps, wd, step, zero_grad, st));
+  return slam_refresh_transposed(h, stream);
+}
+
 int slam_join(SlamEngine* h, slam_stream_t stream) {
   if (!h) return SLAM_EINVAL;
   CK(join_optimizer(h, (hipStream_t)stream));

@@ -71,6 +71,9 @@ int scale_rows_bf16(bf16_t* x, const float* coef, int M, int T, int ncols, hipSt
 int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st);
 int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
           double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
+// bf16 parameters and bf16 moments updated in place (fp32 arithmetic per element, no master copy)
+int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
+               double eps, double wd, int step, int zero_grad, hipStream_t st);
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st);
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st);
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,

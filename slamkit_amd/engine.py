@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None):
         "slam_scale_loss_rows": (C.c_int, [vp, vp, i32, i32, vp]),
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
         "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_adamw_step_bf16": (C.c_int, [vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
@@ -229,6 +230,16 @@ class Engine:
                                           float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                           int(step), int(bool(zero_grad)),
                                           stream if stream is not None else current_stream_ptr()))
+
+    def adamw_step_bf16(self, exp_avg, exp_avg_sq, norm_out, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True,
+                        stream=None):
+        """bf16 parameters + bf16 moments, updated in place (the recipe's optimizer precision)."""
+        import torch
+        assert exp_avg.dtype == torch.bfloat16 and exp_avg_sq.dtype == torch.bfloat16
+        self._ck(self.lib.slam_adamw_step_bf16(self.h, _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(norm_out), float(lr),
+                                               float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                               int(bool(zero_grad)),
+                                               stream if stream is not None else current_stream_ptr()))
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))

@@ -290,9 +290,9 @@ class UnitLM(TokenLM):
         std = float(self.config.base_config["initializer_range"])
         g = torch.Generator(device=self.device).manual_seed(seed)
         self.engine.join()
-        self.flat_master.zero_()
+        self._weights.zero_()
         for k in self.key_map:
-            v = self._view(self.flat_master, k, writable=True)
+            v = self._view(self._weights, k, writable=True)
             if k.endswith("norm.weight"):
                 v.fill_(1.0)
             elif k.endswith(".bias"):
@@ -300,11 +300,25 @@ class UnitLM(TokenLM):
             else:
                 v.normal_(0.0, std, generator=g)
         if self.config.pad_token_id is not None and self.config.pad_token_id >= 0:
-            self._view(self.flat_master, "lm.model.embed_tokens.weight", True)[self.config.pad_token_id].zero_()
+            self._view(self._weights, "lm.model.embed_tokens.weight", True)[self.config.pad_token_id].zero_()
         self.sync_params_from_master()
 
     def sync_params_from_master(self):
-        self.engine.cast_params(self.flat_master)
+        if self.flat_master is not None:
+            self.engine.cast_params(self.flat_master)
+        else:
+            self.engine.refresh_transposed()
+
+    def drop_master(self):
+        """bf16-parameter training (the recipe's precision, slam.yaml:9): the bf16 buffer becomes the only copy of the
+        weights; the optimizer (slam_adamw_step_bf16) updates it in place."""
+        self.engine.join()
+        self.flat_master = None
+
+    @property
+    def _weights(self) -> torch.Tensor:
+        """The authoritative flat weight buffer: fp32 master when there is one, else the bf16 parameters."""
+        return self.flat_master if self.flat_master is not None else self.flat_params
 
     def named_parameters(self) -> Iterator[Tuple[str, torch.Tensor]]:
         self.engine.join()  # a pending overlapped optimizer step writes these buffers on the engine's side stream
@@ -325,7 +339,7 @@ class UnitLM(TokenLM):
 
     def state_dict(self, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
         self.engine.join()
-        src = self.flat_master if dtype == torch.float32 else self.flat_params
+        src = self._weights if dtype == torch.float32 else self.flat_params
         return {k: self._view(src, k).detach().to(dtype).cpu().clone() for k in self.key_map}
 
     @staticmethod
@@ -361,7 +375,7 @@ class UnitLM(TokenLM):
                         src = torch.cat([src.float(), src.float().mean(0, keepdim=True).expand(shp[0] - src.shape[0], -1)])
                 if tuple(src.shape) != tuple(shp):
                     raise ValueError(f"{k}: checkpoint shape {tuple(src.shape)} != model shape {tuple(shp)}")
-                self._assign(self.flat_master, k, src)
+                self._assign(self._weights, k, src)
         self.sync_params_from_master()
         return missing, extra
 

@@ -114,11 +114,7 @@ class SLAMDPOTrainer(SLAMTrainer):
             seen = float(t)
         self.state.num_input_tokens_seen += int(seen)
         self.reducer.finish()
-        eng = self.model.engine
-        eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
-        self.opt_step += 1
-        eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
-                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=True)
+        self._clip_and_update(lr, zero_grad=True)
         self.state.global_step += 1
 
     @torch.no_grad()

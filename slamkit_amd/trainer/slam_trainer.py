@@ -46,10 +46,20 @@ class SLAMTrainer:
         self.rank, self.world = world_info()
         dev = model.device
         n = model.engine.n_params
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        osd = getattr(self.args, "optim_state_dtype", "float32") or "float32"
+        if osd not in ("float32", "bfloat16"):
+            raise ValueError(f"optim_state_dtype must be float32 or bfloat16, got {osd!r}")
+        self.state_dtype = getattr(torch, osd)
+        if self.state_dtype == torch.bfloat16:
+            if getattr(self.args, "overlap_optimizer", False):
+                raise ValueError("overlap_optimizer is implemented for the fp32-state optimizer only")
+            if hasattr(model, "drop_master"):
+                model.drop_master()  # the bf16 parameters become the only copy (the recipe's torch_dtype: bfloat16)
+        self.exp_avg = torch.zeros(n, dtype=self.state_dtype, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=self.state_dtype, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, args.ddp_comm_dtype) if getattr(args, "ddp_comm_dtype", None) else None)
+        cd = getattr(self.args, "ddp_comm_dtype", None)
+        self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)
         self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
@@ -146,12 +156,20 @@ class SLAMTrainer:
         self._loss_n += 1
         self.reducer.finish()
         self.state.num_input_tokens_seen += int(glob_seen)
-        eng = self.model.engine
+        self._clip_and_update(lr, zero_grad=not a.overwrite_first_grad)
+        self.state.global_step += 1
+
+    def _clip_and_update(self, lr: float, zero_grad: bool):
+        """clip_grad_norm_ + AdamW on the flat buffers, in the configured state precision."""
+        a, eng = self.args, self.model.engine
         eng.grad_norm(a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
         self.opt_step += 1
-        eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
-                       a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=not a.overwrite_first_grad)
-        self.state.global_step += 1
+        if self.state_dtype == torch.bfloat16:
+            eng.adamw_step_bf16(self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1, a.adam_beta2,
+                                a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=zero_grad)
+        else:
+            eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
+                           a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=zero_grad)
 
     def _sync_control(self):
         """Callbacks decide from rank-local clocks (RunTimeStopperCallback: `start_time` differs per rank), and
@@ -282,7 +300,7 @@ class SLAMTrainer:
             path = self._ckpt_dir(self.state.global_step)
             self.model.save_pretrained(path)
             self.model.engine.join()
-            torch.save({"master": self.model.flat_master.cpu(), "exp_avg": self.exp_avg.cpu(),
+            torch.save({"master": self.model._weights.cpu(), "exp_avg": self.exp_avg.cpu(),
                         "exp_avg_sq": self.exp_avg_sq.cpu(), "opt_step": self.opt_step}, os.path.join(path, "optimizer.pt"))
             with open(os.path.join(path, "trainer_state.json"), "w") as f:
                 json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch,
@@ -302,7 +320,7 @@ class SLAMTrainer:
     def _load_checkpoint(self, path: str):
         st = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
         self.model.engine.join()
-        self.model.flat_master.copy_(st["master"])
+        self.model._weights.copy_(st["master"])
         self.model.sync_params_from_master()
         self.exp_avg.copy_(st["exp_avg"])
         self.exp_avg_sq.copy_(st["exp_avg_sq"])

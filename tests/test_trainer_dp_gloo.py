@@ -94,7 +94,7 @@ def run_trainer(rank, world, avg_tokens, out_dir):
     from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
     args = SLAMTrainingArguments(output_dir=out_dir, per_device_train_batch_size=2, gradient_accumulation_steps=2,
                                  learning_rate=1e-2, warmup_steps=1, warmup_ratio=0.0, max_steps=3, logging_steps=1,
-                                 average_tokens_across_devices=avg_tokens, ddp_bucket_layers=1, seed=5, save_steps=0)
+                                 average_tokens_across_devices=avg_tokens, ddp_bucket_layers=1, seed=5, save_steps=0, ddp_comm_dtype="float32")
     model = StubLM()
     tr = SLAMTrainer(model=model, args=args, data_collator=DataCollatorForLanguageModeling(pad_token_id=0),
                      train_dataset=make_rows())
