@@ -283,7 +283,8 @@ def main():
                                  learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0,
                                  overlap_optimizer=os.environ.get("SLAM_OVERLAP_OPTIMIZER", "0") == "1",
                                  overwrite_first_grad=os.environ.get("SLAM_OVERWRITE_FIRST_GRAD", "1") == "1",
-                                 ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE") or None)
+                                 ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"),
+                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "float32"))
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
     batches = [[synth_batch(rank, i * a.grad_accum + j, dev) for j in range(a.grad_accum)] for i in range(nb)]
@@ -328,7 +329,9 @@ def main():
                                    "synthetic unit-token stream, random-init weights; full optimizer step",
                        "model": "Slam-358M", "global_batch": world * B * a.grad_accum, "micro_batch": B, "seq_len": T,
                        "grad_accum": a.grad_accum, "parallelism": f"dp{world}",
-                       "optimizer": "AdamW fp32 master+moments, clip 0.5", "final_loss": round(loss, 4),
+                       "optimizer": ("AdamW fp32 master+moments" if args.optim_state_dtype == "float32" else
+                                     "AdamW bf16 parameters+moments (the recipe's precision)") + ", clip 0.5",
+                       "final_loss": round(loss, 4),
                        "exposed_comm_ms_last_step": round(exposed, 3)},
         }
         roof = dominant_kernel_roofline(model)

@@ -363,9 +363,10 @@ __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int B, in
 }
 
 // one wave per row, Vp == 512 (64 lanes x 8)
-__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logits,
+// (logits and dlogits may be the SAME buffer: a lane reads its chunk into registers before it writes it)
+__global__ __launch_bounds__(256) void ce_kernel(const bf16_t* logits,
                                                  const int64_t* __restrict__ labels,
-                                                 const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
+                                                 const float* __restrict__ denom, bf16_t* dlogits,
                                                  float* __restrict__ row_loss, int B, int T, int Vp, int V,
                                                  const uint8_t* __restrict__ colmask) {
   const int lane = threadIdx.x & 63;
@@ -430,9 +431,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_t* __restrict__ logi
 // Large vocabulary (Vp > 512, a multiple of 8): one 256-thread block per row, two passes over the
 // row (online max / sum, then the gradient); the second read hits L2 (a 152k-column row is 300 KB).
 // Algorithmic traffic: 2 B/logit read + 2 B/logit written.
-__global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ logits,
+// (logits and dlogits may be the SAME buffer - the engine's training path: the gradient replaces the logits chunk by
+//  chunk in the second pass, after the barrier behind the first pass and after thread 0 has read the target logit)
+__global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* logits,
                                                      const int64_t* __restrict__ labels,
-                                                     const float* __restrict__ denom, bf16_t* __restrict__ dlogits,
+                                                     const float* __restrict__ denom, bf16_t* dlogits,
                                                      float* __restrict__ row_loss, int B, int T, int Vp, int V,
                                                      const uint8_t* __restrict__ colmask) {
   __shared__ float red_m[4], red_s[4];
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ 
     if (tid == 0) row_loss[m] = 0.f;
     return;
   }
+  const float tgt_logit = tid == 0 ? bf16_to_f32(logits[(size_t)m * Vp + tgt]) : 0.f;  // read before any in-place write
   float mx = -3.0e38f, sm = 0.f;
   for (int c = tid; c < nch; c += 256) {
     float f[8];
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void ce_big_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int w = 0; w < 4; ++w) bs += red_s[w] * __expf(red_m[w] - bm);
   const float lse = bm + logf(bs);
-  if (tid == 0) row_loss[m] = (colmask && colmask[tgt]) ? INFINITY : lse - bf16_to_f32(logits[(size_t)m * Vp + tgt]);
+  if (tid == 0) row_loss[m] = (colmask && colmask[tgt]) ? INFINITY : lse - tgt_logit;
   if (dl) {
     const float sc = 1.f / denom[0];
     for (int c = tid; c < nch; c += 256) {

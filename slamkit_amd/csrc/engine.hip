@@ -73,7 +73,18 @@ struct SlamEngine {
   std::vector<hipEvent_t> ev_chunk;  // [0] embedding, [1 + l] layer l, [L + 1] final norm
   bool opt_pending = false;
 
+  // "bwd_wgrad_stream": the weight-gradient GEMMs of backward run on a second engine-owned stream. They are off the
+  // critical path (nothing in backward reads a weight gradient), so their blocks fill the CU slots the dgrad / attention
+  // chain leaves idle: the N = 896 launches occupy 448 of 512 block slots, and a kernel in its HBM-bound epilogue
+  // (down-proj dgrad with the fused SwiGLU backward) leaves the MFMA pipes free. Event pairs order every wgrad after the
+  // kernel that produces its operands and every buffer re-use on the main stream after the wgrad that reads it.
+  int wgrad_stream = 0;
+  hipStream_t wside = nullptr;
+  std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
+
   ~SlamEngine() {
+    if (wside) { (void)hipStreamSynchronize(wside); (void)hipStreamDestroy(wside); }
+    for (hipEvent_t e : ev_w) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
@@ -146,8 +157,10 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->hf = c.take<bf16_t>(M * H);
   e->rstdf = c.take<float>(M);
   const size_t VP = (size_t)e->vpad;
+  // ONE [M][Vp] buffer: the loss kernel replaces the logits with d loss / d logits in place (2 x 5 GB -> 5 GB at
+  // M = 16384, Vp = 152,320); callers that want the logits get their copy before the loss runs
   e->logits = c.take<bf16_t>(M * VP);
-  e->dlogits = c.take<bf16_t>(M * VP);
+  e->dlogits = e->logits;
   if (e->vpad == VPAD_SMALL) { e->onehot = c.take<bf16_t>(M * VP); e->embed_ws = nullptr; }
   else { e->onehot = nullptr; e->embed_ws = c.take<int>(embed_bwd_workspace_ints((int)M, e->vpad)); }
   e->row_loss = c.take<float>(M);
@@ -208,6 +221,17 @@ int ensure_side(SlamEngine* h) {
   if (e != hipSuccess) return (int)e;
   h->ev_chunk.resize(h->d.n_layers + 2);
   for (auto& ev : h->ev_chunk) {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+int ensure_wside(SlamEngine* h) {
+  if (h->wside) return 0;
+  hipError_t e = hipStreamCreateWithFlags(&h->wside, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
+  for (auto& ev : h->ev_w) {
     e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;
   }
@@ -337,9 +361,11 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_256_dswiglu")) { gemm_set_256_dswiglu((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -401,13 +427,13 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
   const int VP = h->vpad;
   CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
   h->have_loss = false;
+  if (logits_out) CK(copy_cols(h->logits, VP, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
   if (labels) {
     CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VP,
                      d.vocab, h->logit_mask, st));
     CK((int)hipMemcpyAsync(loss_out, h->scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     h->have_loss = true;
   }
-  if (logits_out) CK(copy_cols(h->logits, VP, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
   h->B = B;
   h->T = T;
   h->last_ids = ids;
@@ -442,7 +468,25 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // zeroing pass (4 B/param written by AdamW + 4 B/param re-read by the wgrad epilogues)
   const int acc = h->overwrite_next ? 0 : 1;
   h->overwrite_next = false;
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, st));
+
+  // weight-gradient launches: on the main stream, or (bwd_wgrad_stream) on the side stream `ws` behind an event that the
+  // main stream records once their operands exist. slot = (layer index, or L for the head / embedding) * 8 + k:
+  // k 0..3 main->side "operands ready" (wd, wgu, wo, wqkv), k 4..6 side->main "done reading" (dh, dh2, dqkv)
+  const bool two = h->wgrad_stream != 0;
+  if (two) CK(ensure_wside(h));
+  hipStream_t ws = two ? h->wside : st;
+  auto ev = [&](int layer, int k) { return h->ev_w[(size_t)layer * 8 + k]; };
+  auto fork = [&](int layer, int k) -> int {  // side stream continues after everything enqueued on main so far
+    if (!two) return 0;
+    hipError_t e = hipEventRecord(ev(layer, k), st);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamWaitEvent(ws, ev(layer, k), 0);
+  };
+  auto mark = [&](int layer, int k) -> int { return two ? (int)hipEventRecord(ev(layer, k), ws) : 0; };
+  auto wait_side = [&](int layer, int k) -> int { return two ? (int)hipStreamWaitEvent(st, ev(layer, k), 0) : 0; };
+
+  CK(fork(L, 0));
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, ws));
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
@@ -455,24 +499,34 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
     // MLP
-    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, st));
+    CK(fork(l, 0));
+    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, ws));
+    CK(mark(l, 4));  // dh has been read by the wgrad
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
     } else {
       CK(dgrad(dh, o.wd, h->dact, H, I));
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
-    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, st));
+    CK(fork(l, 1));
+    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, ws));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
+    if (l + 1 < L) CK(wait_side(l + 1, 5));  // the previous layer's wo wgrad still reads dh2
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, st));
+    CK(fork(l, 2));
+    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, ws));
+    CK(mark(l, 5));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
+    if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
     CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->cosb, h->sinb, M,
                 nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, st));
+    CK(fork(l, 3));
+    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, ws));
+    CK(mark(l, 6));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
+    CK(wait_side(l, 4));  // this layer's wd wgrad still reads dh
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
     // bucket boundaries: every `bl` layers from the top, and after each of the last two layers so that the
     // final all-reduce (exposed behind the end of backward) only carries layer 0 + the embedding
@@ -487,18 +541,23 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       fin_hi = l;
     }
     if (boundary) {
+      CK(wait_side(l, 6));  // the side stream is in order: its last launch of layer l covers every wgrad of the range
       cb(user, o.ln1, bucket_end - o.ln1);
       bucket_end = o.ln1;
     }
   }
   // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
   // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
+  // (on the wgrad stream: ordered after the head's contribution to the same rows)
+  CK(fork(L, 1));
   if (VP == VPAD_SMALL) {
-    CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, st));
-    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, st));
+    CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
+    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, ws));
   } else {
-    CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, st));
+    CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
   }
+  CK(mark(L, 4));
+  CK(wait_side(L, 4));  // join: everything after slam_backward on `stream` sees complete gradients
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;

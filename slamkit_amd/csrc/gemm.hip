@@ -986,6 +986,10 @@ static bool use_256(const GemmArgs& a) {
   if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
   return tiles >= 256 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.74;
 }
+// the down-proj dgrad with the fused SwiGLU backward on the 256 x 256 kernel (1) or on the 128 x 128 kernel (0: two blocks
+// per CU, so that one block's HBM-bound epilogue sits beside another block's - or a concurrent wgrad's - MFMA loop)
+static int g_gemm_256_dswiglu = 1;
+void gemm_set_256_dswiglu(int on) { g_gemm_256_dswiglu = on; }
 static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
 void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
 static int launch_256(GemmArgs a, hipStream_t st) {
@@ -1049,6 +1053,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
   GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
+  if (!g_gemm_256_dswiglu) return launch<false, false, false, true, true>(a, 1, st);
   return launch_nt_dma(a, st);
 }
 

@@ -15,6 +15,7 @@ void gemm_set_tn_splits(int s);
 void gemm_set_group_rows(int g);
 void gemm_set_nt_store(int on);
 void gemm_set_256(int on);
+void gemm_set_256_dswiglu(int on);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
