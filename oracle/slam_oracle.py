@@ -157,8 +157,9 @@ def attention_mask_bool(B, T, attention_mask=None, position_ids=None, packed=Fal
     return m
 
 
-def attention(q, k, v, mask, scale):
-    """eager_attention_forward with repeat_kv, hf: modeling_qwen2.py:138-172 (softmax in fp32)."""
+def attention(q, k, v, mask, scale, bf16_probs: bool = False):
+    """eager_attention_forward with repeat_kv, hf: modeling_qwen2.py:138-172 (softmax in fp32; the probabilities are cast
+    to the value dtype before P V - emulated with bf16_probs when the tensors are fp32 stand-ins for bf16 ones)."""
     B, nH, T, hd = q.shape
     rep = nH // k.shape[1]
     k = k.repeat_interleave(rep, dim=1)
@@ -166,13 +167,26 @@ def attention(q, k, v, mask, scale):
     s = torch.matmul(q, k.transpose(2, 3)) * scale
     s = s.masked_fill(~mask[:, None], torch.finfo(s.dtype).min)
     p = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+    if bf16_probs:
+        p = _bf16_round(p)
     return torch.matmul(p, v).transpose(1, 2).contiguous()
 
 
+def _bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """Value rounded to bf16 (kept in fp32 storage), identity gradient."""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
 def decoder_stack(cfg: OracleConfig, sd: Dict[str, torch.Tensor], h: torch.Tensor, E_head: torch.Tensor,
-                  attention_mask=None, position_ids=None, packed=False):
+                  attention_mask=None, position_ids=None, packed=False, bf16_acts: bool = False):
     """Qwen2Model layers + final norm + tied head on given input embeddings
-    (hf: modeling_qwen2.py:342-402, DecoderLayer :269-298, Attention :189-233, MLP :41-48, head :465)."""
+    (hf: modeling_qwen2.py:342-402, DecoderLayer :269-298, Attention :189-233, MLP :41-48, head :465).
+    bf16_acts=True restates the reference's OWN precision (bf16 parameters under bf16 autocast, slam.yaml:9 +
+    training_args bf16): every module output the HF path materialises as a bf16 tensor - Linear outputs, RMSNorm
+    outputs, rotated q / k, attention probabilities and output, the SwiGLU product, residual sums, logits - is rounded
+    to bf16 at that point (arithmetic inside a module stays fp32, as the GPU kernels accumulate). Used to calibrate how
+    far ANY bf16 implementation sits from the fp32 run at a given depth / width (tests/test_gpu_model.py)."""
+    r = _bf16_round if bf16_acts else (lambda t: t)
     B, T, _ = h.shape
     hd, nH, nKV = cfg.head_dim, cfg.n_heads, cfg.n_kv_heads
     if position_ids is None:
@@ -181,27 +195,28 @@ def decoder_stack(cfg: OracleConfig, sd: Dict[str, torch.Tensor], h: torch.Tenso
     mask = attention_mask_bool(B, T, attention_mask, position_ids, packed)
     for l in range(cfg.n_layers):
         p = f"lm.model.layers.{l}."
-        x = rms_norm(h, sd[p + "input_layernorm.weight"], cfg.rms_eps)
-        q = F.linear(x, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(B, T, nH, hd).transpose(1, 2)
-        k = F.linear(x, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(B, T, nKV, hd).transpose(1, 2)
-        v = F.linear(x, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(B, T, nKV, hd).transpose(1, 2)
+        x = r(rms_norm(h, sd[p + "input_layernorm.weight"], cfg.rms_eps))
+        q = r(F.linear(x, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"])).view(B, T, nH, hd).transpose(1, 2)
+        k = r(F.linear(x, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])).view(B, T, nKV, hd).transpose(1, 2)
+        v = r(F.linear(x, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])).view(B, T, nKV, hd).transpose(1, 2)
         q, k = apply_rope(q, k, cos, sin)
-        a = attention(q, k, v, mask, hd ** -0.5).reshape(B, T, nH * hd)
-        h = h + F.linear(a, sd[p + "self_attn.o_proj.weight"])
-        x = rms_norm(h, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = F.linear(x, sd[p + "mlp.gate_proj.weight"])
-        u = F.linear(x, sd[p + "mlp.up_proj.weight"])
-        h = h + F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"])
-    hf = rms_norm(h, sd["lm.model.norm.weight"], cfg.rms_eps)
-    return F.linear(hf, E_head)  # tied lm_head, hf: modeling_qwen2.py:407,465
+        q, k = r(q), r(k)
+        a = r(attention(q, k, v, mask, hd ** -0.5, bf16_probs=bf16_acts).reshape(B, T, nH * hd))
+        h = r(h + r(F.linear(a, sd[p + "self_attn.o_proj.weight"])))
+        x = r(rms_norm(h, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps))
+        g = r(F.linear(x, sd[p + "mlp.gate_proj.weight"]))
+        u = r(F.linear(x, sd[p + "mlp.up_proj.weight"]))
+        h = r(h + r(F.linear(r(F.silu(g) * u), sd[p + "mlp.down_proj.weight"])))
+    hf = r(rms_norm(h, sd["lm.model.norm.weight"], cfg.rms_eps))
+    return r(F.linear(hf, E_head))  # tied lm_head, hf: modeling_qwen2.py:407,465
 
 
 def model_forward(cfg: OracleConfig, sd: Dict[str, torch.Tensor], input_ids: torch.Tensor,
                   attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-                  packed: bool = False):
+                  packed: bool = False, bf16_acts: bool = False):
     """UnitLM.forward -> Qwen2ForCausalLM.forward without labels (unit_lm.py:155-167)."""
     E = sd["lm.model.embed_tokens.weight"]
-    return decoder_stack(cfg, sd, F.embedding(input_ids, E), E, attention_mask, position_ids, packed)
+    return decoder_stack(cfg, sd, F.embedding(input_ids, E), E, attention_mask, position_ids, packed, bf16_acts)
 
 
 def compute_loss(logits: torch.Tensor, labels: torch.Tensor, num_items_in_batch=None, ignore_index: int = -100):

@@ -78,7 +78,7 @@ struct SlamEngine {
   // chain leaves idle: the N = 896 launches occupy 448 of 512 block slots, and a kernel in its HBM-bound epilogue
   // (down-proj dgrad with the fused SwiGLU backward) leaves the MFMA pipes free. Event pairs order every wgrad after the
   // kernel that produces its operands and every buffer re-use on the main stream after the wgrad that reads it.
-  int wgrad_stream = 0;
+  int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
   hipStream_t wside = nullptr;
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
@@ -364,6 +364,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_256_dswiglu")) { gemm_set_256_dswiglu((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn224")) { gemm_set_tn224((int)value); return SLAM_OK; }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }

@@ -933,6 +933,258 @@ __global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actua
   *reinterpret_cast<float4*>(p.dW + off) = s;
 }
 
+
+// ---- wgrad on 256 x 224 tiles, 8 waves, 8-phase schedule ----------------------------------------------------------------
+// The two big weight gradients of a layer (gate|up: [9728][896], down: [896][4864]; contraction over the M = 8192 tokens)
+// hold 88 % of the wgrad flops and ran at ~930 TFLOP/s on the 128 x 128 one-barrier kernel. Every big matrix of the model
+// has one dimension of 896 = 4 x 224 (and 1536-wide models one of 8960 = 40 x 224), so the phase-scheduled structure of
+// gemm_nt_256_kernel is rebuilt here on 256 x 224 tiles: eight waves as 4 (256-side, 64 each) x 2 (224-side, 112 each),
+// a wave owns 64 x 112 of the output (28 fragments, 112 accumulator VGPRs), 22 fragment reads per 56 MFMAs of a K-tile
+// (128 x 128 kernel: 16 per 32). Both operands are stored contraction-major ([M][.]): they are DMA'd as stored into
+// [64 kc][128 columns] half-tile images (256-B rows, 32-B block swizzle keyed by kc) and read with ds_read_b64_tr_b16,
+// exactly the fragment addressing of gemm_tn_bal_kernel. A K-tile is four phases, one output quadrant of the wave each:
+//   half-tiles  H0 = A columns 0..127 | H1 = B columns 0..127 | H2 = B columns 128..223 (96 of the 128 image columns
+//               used) | H3 = A columns 128..255: every kc row of a half-tile is ONE contiguous 256-B (192-B) piece of the
+//               stored operand. Wave row wr owns A columns {32 wr .. +31} of BOTH halves (its fragments 0,1 and 2,3), wave
+//               column wc owns B columns {64 wc .. +63} of H1 and {128 + 48 wc .. +47} of H2.
+//   phase 1: H0 + H1 -> (A0, B0) 16 MFMAs   2: H2 -> (A0, B1) 12   3: H3 -> (A1, B1) 12   4: H1 again (registers) -> (A1, B0) 16
+// with the DMA of one half-tile of the next K-tile issued per phase, counted vmcnt(4), raised MFMA priority and the
+// second wave column one barrier behind the first - the synchronisation skeleton of gemm_nt_256_kernel, unchanged.
+// Work split: balanced K-splitting over the 256 CU slots (one block per CU): piece 0 of a tile accumulates straight into
+// dW, later pieces go to fp32 slabs that reduce_224_kernel adds in piece order (no atomics, the same bits every run).
+struct Tn224Args {
+  const bf16_t* A;   // 256-side operand [M][lda]
+  const bf16_t* B;   // 224-side operand [M][ldb]
+  float* dW;         // element (i on the 256 side, j on the 224 side) at TR ? dW[j * ldw + i] : dW[i * ldw + j]
+  float* slab;       // [slab index][256 * 224] fp32, tile-local in the orientation of dW
+  int lda, ldb, ldw;
+  int tiles_a, tiles_b, KS;
+  int T_A, S_A, per_A, T_B, S_B, per_B, nA;
+  int accumulate;
+};
+SLAM_DEVICE void tn224_tile(int t, int tiles_b, int& ta, int& tb) { ta = t / tiles_b; tb = t - ta * tiles_b; }
+
+template <bool TR>
+__global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HT = 64 * 256;  // half-tile image: 64 kc rows x 256 B
+  constexpr int KT = 4 * HT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 3, wc = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  // ---- which piece of which tile ----
+  int t, ks0, ks1, z;
+  size_t slab_idx = 0;
+  {
+    int b = blockIdx.x;
+    if (b < p.nA) {
+      z = b / p.T_A;
+      const int idx = b - z * p.T_A;
+      // block b runs on XCD b % 8: give each XCD a contiguous run of tiles
+      const int xcd = idx & 7, i8 = idx >> 3, q = p.T_A >> 3, r = p.T_A & 7;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i8;
+      ks0 = z * p.per_A;
+      ks1 = min(p.KS, ks0 + p.per_A);
+      if (z > 0) slab_idx = (size_t)(z - 1) * p.T_A + t;
+    } else {
+      b -= p.nA;
+      z = b / p.T_B;
+      const int idx = b - z * p.T_B;
+      t = p.T_A + idx;
+      ks0 = z * p.per_B;
+      ks1 = min(p.KS, ks0 + p.per_B);
+      if (z > 0) slab_idx = (size_t)(p.S_A - 1) * p.T_A + (size_t)(z - 1) * p.T_B + idx;
+    }
+  }
+  int ta, tb;
+  tn224_tile(t, p.tiles_b, ta, tb);
+  const int a0 = ta * 256, b0 = tb * 224;
+  const int nk = ks1 - ks0;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- DMA source offsets: 2 chunks of 16 B per lane per half-tile. LDS chunk P = i * 512 + tid sits in kc row P >> 4 at
+  //      16-byte slot P & 15 and holds the source chunk (slot ^ (tr_key(kc) << 1)) of that row (32-B block swizzle) ----
+  uint32_t vo[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int P = i * 512 + tid, kc = P >> 4, c = (P & 15) ^ (tr_key(kc) << 1);
+    const int r = c * 8;  // first image column of the chunk
+    const int colA0 = a0 + r, colA1 = a0 + 128 + r;
+    const int colB0 = b0 + r;
+    const int colB1 = b0 + 128 + (r < 96 ? r : 88);  // image columns 96..127 of H2 are unused: they repeat the last chunk
+    vo[0][i] = (uint32_t)(((size_t)kc * p.lda + colA0) * sizeof(bf16_t));
+    vo[3][i] = (uint32_t)(((size_t)kc * p.lda + colA1) * sizeof(bf16_t));
+    vo[1][i] = (uint32_t)(((size_t)kc * p.ldb + colB0) * sizeof(bf16_t));
+    vo[2][i] = (uint32_t)(((size_t)kc * p.ldb + colB1) * sizeof(bf16_t));
+  }
+  const bf16_t* Ak = p.A + (size_t)ks0 * BK * p.lda;
+  const bf16_t* Bk = p.B + (size_t)ks0 * BK * p.ldb;
+  auto issue_half = [&](int h, int t_) {
+    const bf16_t* base = (h == 0 || h == 3) ? Ak + (size_t)t_ * BK * p.lda : Bk + (size_t)t_ * BK * p.ldb;
+    const uint32_t dst = lds0 + (uint32_t)((t_ & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
+  };
+
+  f32x4_t acc[4][7];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragments by transpose reads (lane (l15, g) of 16-column block Pb, K-half kk: kc = 32 kk + 8 g + (l15 >> 2) and + 4) ----
+  const int trk = (l15 >> 2) | ((g & 1) << 2);
+  const int tr_lane = (g * 8 + (l15 >> 2)) * 256 + (l15 & 3) * 8;
+  auto frag = [&](const char* img, int Pb, int kk) -> uint4 {
+    const char* q = img + tr_lane + kk * 32 * 256 + ((Pb ^ trk) << 5);
+    const uint2 lo = lds_tr_read(q), hi = lds_tr_read(q + 4 * 256);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+  uint4 afr[2][2], bg0[2][4], bg1[2][3];  // [kk][fragment]
+  auto read_A = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) afr[kk][f] = frag(img, wr * 2 + f, kk);
+  };
+  auto read_B0 = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) bg0[kk][f] = frag(img, wc * 4 + f, kk);
+  };
+  auto read_B1 = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) bg1[kk][f] = frag(img, wc * 3 + f, kk);
+  };
+  // TR: lane holds 4 consecutive 256-side indices of one 224-side index (a-operand = A fragment); else the reverse
+  auto mma0 = [&](int ah) {  // A half `ah` x B group 0 (fragments 0..3)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+          acc[ah * 2 + fm][fn] = TR ? mfma16(afr[kk][fm], bg0[kk][fn], acc[ah * 2 + fm][fn])
+                                    : mfma16(bg0[kk][fn], afr[kk][fm], acc[ah * 2 + fm][fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma1 = [&](int ah) {  // A half `ah` x B group 1 (fragments 4..6)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 3; ++fn)
+          acc[ah * 2 + fm][4 + fn] = TR ? mfma16(afr[kk][fm], bg1[kk][fn], acc[ah * 2 + fm][4 + fn])
+                                        : mfma16(bg1[kk][fn], afr[kk][fm], acc[ah * 2 + fm][4 + fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](int t_, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const char* buf = smem + (t_ & 1) * KT;
+    // phase 1
+    if (!LAST) issue_half(0, t_ + 1);
+    read_A(buf);
+    read_B0(buf + HT);
+    wait_ph<LAST>(0);  // H2(t) landed -> read in phase 2
+    raw_barrier();
+    mma0(0);
+    raw_barrier();
+    // phase 2
+    if (!LAST) issue_half(1, t_ + 1);
+    read_B1(buf + 2 * HT);
+    wait_ph<LAST>(1);  // H3(t) landed -> read in phase 3
+    raw_barrier();
+    mma1(0);
+    raw_barrier();
+    // phase 3
+    if (!LAST) issue_half(2, t_ + 1);
+    read_A(buf + 3 * HT);
+    raw_barrier();
+    mma1(1);
+    raw_barrier();
+    // phase 4
+    if (!LAST) issue_half(3, t_ + 1);
+    wait_ph<LAST>(2);  // H0(t+1), H1(t+1) landed -> read in phase 1 of the next K-tile
+    raw_barrier();
+    mma0(1);
+    raw_barrier();
+  };
+  if (nk > 0) {
+    issue_half(0, 0);
+    issue_half(1, 0);
+    issue_half(2, 0);
+    issue_half(3, 0);
+    wait_vmcnt<4>();
+    raw_barrier();
+    if (wc == 1) raw_barrier();  // second wave column: one barrier behind from here on
+    for (int t_ = 0; t_ + 1 < nk; ++t_) ktile(t_, std::false_type{});
+    ktile(nk - 1, std::true_type{});
+    if (wc == 0) raw_barrier();  // balance the barrier count
+  }
+
+  // ---- epilogue: piece 0 adds into / stores dW, later pieces fill their slab ----
+  const bool direct = z == 0;
+  const bool add = direct && p.accumulate;
+  float* base;
+  int ld;
+  if (direct) {
+    base = TR ? p.dW + (size_t)b0 * p.ldw + a0 : p.dW + (size_t)a0 * p.ldw + b0;
+    ld = p.ldw;
+  } else {
+    base = p.slab + slab_idx * (size_t)(256 * 224);
+    ld = TR ? 256 : 224;
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    float4 old[7];
+    float* ptr[7];
+#pragma unroll
+    for (int fn = 0; fn < 7; ++fn) {
+      const int i = (fm >> 1) * 128 + wr * 32 + (fm & 1) * 16;
+      const int j = fn < 4 ? wc * 64 + fn * 16 : 128 + wc * 48 + (fn - 4) * 16;
+      ptr[fn] = TR ? base + (size_t)(j + l15) * ld + i + g * 4 : base + (size_t)(i + l15) * ld + j + g * 4;
+      if (add) old[fn] = *reinterpret_cast<const float4*>(ptr[fn]);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 7; ++fn) {
+      const f32x4_t v = acc[fm][fn];
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
+      *reinterpret_cast<float4*>(ptr[fn]) = o;
+    }
+  }
+}
+
+// dW tile t += its slabs (pieces 1..S-1) in piece order; grid (56, tiles): thread = 4 consecutive tile-local elements
+template <bool TR>
+__global__ __launch_bounds__(256) void reduce_224_kernel(Tn224Args p, int SA_act, int SB_act) {
+  const int t = blockIdx.y;
+  const bool inA = t < p.T_A;
+  const int S = inA ? SA_act : SB_act;
+  if (S <= 1) return;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // tile-local element, row-major in the slab orientation
+  constexpr int LD = TR ? 256 : 224;
+  const int r = e / LD, c = e - r * LD;
+  int ta, tb;
+  tn224_tile(t, p.tiles_b, ta, tb);
+  float* dst = TR ? p.dW + (size_t)(tb * 224 + r) * p.ldw + ta * 256 + c : p.dW + (size_t)(ta * 256 + r) * p.ldw + tb * 224 + c;
+  float4 s = *reinterpret_cast<const float4*>(dst);
+  const size_t stride = (size_t)(inA ? p.T_A : p.T_B) * (256 * 224);
+  const float* src = p.slab + (inA ? (size_t)t : (size_t)(p.S_A - 1) * p.T_A + (size_t)(t - p.T_A)) * (256 * 224) + e;
+  for (int k = 0; k + 1 < S; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(src + k * stride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dst) = s;
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
                                      int splits, int accumulate) {
@@ -1121,6 +1373,100 @@ static BalPlan tn_bal_plan(int M, int N, int K) {
   }
   return best;
 }
+
+// ---- 256 x 224 phase-scheduled wgrad: shape test, balanced plan, launch -------------------------------------------------
+// tn224: 0 = off, 1 = when the plan fills the chip (default), 2 = whenever the shape allows (tests)
+static int g_tn224 = 1;
+void gemm_set_tn224(int v) { g_tn224 = v; }
+struct Plan224 { int T_A, S_A, per_A, T_B, S_B, per_B, slabs; bool tr; int tiles_a, tiles_b; };
+// orientation: 0 = none, 1 = dW[n][k] with n on the 256 side (N % 256 == 0, K % 224 == 0), 2 = transposed store (k on the 256 side)
+static int tn224_orient(int M, int N, int K) {
+  if (!g_tn224 || (M % BK)) return 0;
+  const bool o1 = (N % 256 == 0) && (K % 224 == 0), o2 = (K % 256 == 0) && (N % 224 == 0);
+  if (!o1 && !o2) return 0;
+  const long tiles = (long)N * K / (256 * 224);
+  // Measured (MI355X, round 2): the main loop runs 1.24 PFLOP/s against 0.96 for the 128 x 128 kernel on a 65,536-long
+  // contraction, but at M = 8192 every piece is 13..64 K-steps long and the one-block-per-CU epilogue (229 KB of fp32 per
+  // piece, nothing to overlap it with) plus the slab pass give the gain back: gate|up weight 148-157 us vs 149-153,
+  // down weight 77 vs 86 us, Slam-358M step 291.1k vs 294.3k tok/s. Default: contractions of 16,384 tokens and more.
+  if (g_tn224 != 2 && (tiles < 64 || M < 16384)) return 0;
+  return o1 ? 1 : 2;
+}
+static Plan224 tn224_plan(int M, int N, int K, int orient) {
+  Plan224 best{};
+  const int SLOTS = 256;  // one block per CU
+  const int T = (N / (orient == 1 ? 256 : 224)) * (K / (orient == 1 ? 224 : 256)), KS = M / BK;
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  const int OVH = 3;  // K-steps' worth of prologue + epilogue per piece
+  int best_cost = 1 << 30;
+  auto consider = [&](int S, int T_A) {
+    if (S < 1 || S > 16 || S > KS || T_A < 0 || T_A > T) return;
+    Plan224 pl{};
+    pl.T_A = T_A; pl.per_A = cdiv(KS, S); pl.S_A = T_A ? cdiv(KS, pl.per_A) : 1;
+    pl.T_B = T - T_A; pl.S_B = 1; pl.per_B = KS;
+    int cost = T_A ? cdiv(T_A * pl.S_A, SLOTS) * (pl.per_A + OVH) : 0;
+    if (pl.T_B) {
+      int sb = SLOTS / pl.T_B;
+      if (sb > 16) sb = 16;
+      if (sb < 1) sb = 1;
+      if (sb > KS) sb = KS;
+      pl.per_B = cdiv(KS, sb); pl.S_B = cdiv(KS, pl.per_B);
+      cost += cdiv(pl.T_B * pl.S_B, SLOTS) * (pl.per_B + OVH);
+    }
+    pl.slabs = (pl.S_A - 1) * pl.T_A + (pl.S_B - 1) * pl.T_B;
+    // slab traffic (written in the kernel, read by the reduce): ~0.12 K-steps of this kernel per MB
+    cost += (int)(0.12 * pl.slabs * (256 * 224 * 4) / 1e6);
+    if (cost < best_cost) { best_cost = cost; best = pl; }
+  };
+  for (int S = 1; S <= 16; ++S) {
+    consider(S, T);
+    const int full = (T * S / SLOTS) * SLOTS / S;
+    if (full > 0 && full < T) consider(S, full);
+  }
+  best.tr = orient == 2;
+  best.tiles_a = orient == 1 ? N / 256 : K / 256;
+  best.tiles_b = orient == 1 ? K / 224 : N / 224;
+  return best;
+}
+static size_t tn224_workspace_bytes(int M, int N, int K) {
+  const int o = tn224_orient(M, N, K) ? tn224_orient(M, N, K) : 0;
+  // sized as if forced (g_tn224 == 2 may be switched on later by a test): any eligible shape reserves its slabs
+  const bool o1 = (M % BK == 0) && (N % 256 == 0) && (K % 224 == 0), o2 = (M % BK == 0) && (K % 256 == 0) && (N % 224 == 0);
+  (void)o;
+  if (!o1 && !o2) return 0;
+  const Plan224 pl = tn224_plan(M, N, K, o1 ? 1 : 2);
+  return (size_t)pl.slabs * 256 * 224 * sizeof(float);
+}
+static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
+                        float* ws, int orient, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const Plan224 pl = tn224_plan(M, N, K, orient);
+  Tn224Args a{};
+  a.A = orient == 1 ? dY : X; a.lda = orient == 1 ? ldy : ldx;
+  a.B = orient == 1 ? X : dY; a.ldb = orient == 1 ? ldx : ldy;
+  a.dW = dW; a.ldw = K; a.slab = ws;
+  a.tiles_a = pl.tiles_a; a.tiles_b = pl.tiles_b; a.KS = M / BK;
+  a.T_A = pl.T_A; a.S_A = pl.S_A; a.per_A = pl.per_A; a.T_B = pl.T_B; a.S_B = pl.S_B; a.per_B = pl.per_B;
+  a.nA = pl.T_A * pl.S_A;
+  a.accumulate = accumulate;
+  const int nblk = a.nA + pl.T_B * pl.S_B;
+  const int T = pl.T_A + pl.T_B;
+  if (pl.tr) {
+    gemm_tn_224_kernel<true><<<nblk, 512, 8 * 64 * 256, st>>>(a);
+    if (pl.slabs) reduce_224_kernel<true><<<dim3(56, T), 256, 0, st>>>(a, pl.S_A, pl.S_B);
+  } else {
+    gemm_tn_224_kernel<false><<<nblk, 512, 8 * 64 * 256, st>>>(a);
+    if (pl.slabs) reduce_224_kernel<false><<<dim3(56, T), 256, 0, st>>>(a, pl.S_A, pl.S_B);
+  }
+  return (int)hipGetLastError();
+}
+
 size_t gemm_tn_workspace_bytes(int M, int N, int K) {
   size_t split = (size_t)gemm_tn_splits(M, N, K) * N * K * sizeof(float);
   if ((N % BM == 0) && (K % BN == 0) && (M % BK == 0)) {
@@ -1128,6 +1474,8 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K) {
     size_t bal = ((pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0) + (size_t)pl.SB_act * pl.T_B * 128 * 128) * sizeof(float);
     if (bal > split) split = bal;
   }
+  const size_t t224 = tn224_workspace_bytes(M, N, K);
+  if (t224 > split) split = t224;
   return split;
 }
 
@@ -1135,6 +1483,7 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K) {
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
             int ldx, float* ws, hipStream_t st) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
+  if (const int orient = tn224_orient(M, N, K)) return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, st);
   if (tn_bal_ok(M, N, K)) {
     static bool attr = false;
     if (!attr) {

@@ -18,6 +18,7 @@ void gemm_set_256(int on);
 void gemm_set_256_dswiglu(int on);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
+void gemm_set_tn224(int v);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks

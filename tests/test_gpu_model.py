@@ -234,7 +234,7 @@ def _check_all_grads(m, grads_ref, tag, big=0.999, small=0.99):
 
 def test_slam358m_loss_and_grads_vs_oracle():
     """Full-size Slam-358M (24 L, H 896, 14/2 heads, I 4864, V 502) at the full context length (B 1, T 1024) against the
-    fp32 CPU oracle: loss, logits and EVERY one of the 291 gradient tensors."""
+    fp32 CPU oracle: loss, logits and EVERY one of the 290 gradient tensors."""
     B, T = 1, 1024
     cfg = O.SLAM_358M
     sd = O.init_weights(cfg, seed=0)
@@ -252,7 +252,7 @@ def test_slam358m_loss_and_grads_vs_oracle():
     print("slam358m loss engine/oracle", float(out.loss), float(loss_ref))
     assert abs(float(out.loss) - float(loss_ref)) <= 2e-2
     check("slam358m logits", out.logits.float().cpu(), logits_ref, 2e-2)
-    assert len(list(m.named_grads())) == 291
+    assert len(list(m.named_grads())) == 290
     _check_all_grads(m, grads_ref, "Slam-358M T=1024")
 
     # ---- size-independent properties at the BASELINE.json shape (B=8, T=1024) ----------------
@@ -412,7 +412,7 @@ def test_configs3_full_depth_packed_vs_oracle():
     """The interleaved speech-text model at full depth and full vocabulary (Qwen2.5-1.5B body: 28 L, H 1536, 12/2 heads of
     128, I 8960, rope_theta 1e6; V = 152,167) on ONE packed row of 2048 tokens in four segments (the longest spans
     1100 tokens, i.e. beyond any single 1024 window) against the fp32 CPU oracle: loss <= 2e-2, logits rel-RMS <= 2e-2,
-    gradient cosine on ALL 339 tensors. Then the 16,384-token packed micro-batch of the bench workload through the
+    gradient cosine on ALL 338 tensors. Then the 16,384-token packed micro-batch of the bench workload through the
     size-independent properties: bit-identical repeat, and invariance under a permutation of the packed segments."""
     cfg = O.OracleConfig(n_layers=28, hidden=1536, n_heads=12, n_kv_heads=2, head_dim=128, intermediate=8960, vocab=152167,
                          rope_theta=1000000.0)
@@ -441,7 +441,7 @@ def test_configs3_full_depth_packed_vs_oracle():
     assert abs(float(out.loss) - float(loss_ref)) <= 2e-2
     check("configs[3] logits", out.logits.float().cpu(), logits_ref, 2e-2)
     del logits_ref
-    assert len(list(m.named_grads())) == 339
+    assert len(list(m.named_grads())) == 338
     _check_all_grads(m, grads_ref, "configs[3] 28 L, V 152167, packed 2048")
     del grads_ref
 

@@ -88,6 +88,33 @@ def test_gemm_tn(M, N, K):
     check(f"gemm_tn accumulate {M}x{N}x{K}", dW, 2 * ref, 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 224), (320, 512, 448), (2048, 768, 672), (1024, 224, 512), (4096, 448, 1024),
+                                   (8192, 9728, 896), (8192, 896, 4864)])
+def test_gemm_tn_224_phase_scheduled(M, N, K):
+    """256 x 224 / 8-wave / 8-phase wgrad kernel (both store orientations, forced on: every split plan from one piece to
+    16 pieces per tile occurs across these shapes) against the fp32 reference and - bit for bit across repeats - itself."""
+    dY, X = rnd(M, N, seed=8), rnd(M, K, seed=9)
+    a, b = dev_bf16(dY), dev_bf16(X)
+    ref = dY.t() @ X
+    try:
+        assert lib().slam_set_option(None, b"gemm_tn224", 2) == 0
+        ws = torch.empty(lib().slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device="cuda")
+        outs = []
+        for rep in range(3):
+            ws.fill_(float("nan"))
+            dW = torch.full((N, K), 1.0, dtype=torch.float32, device="cuda")
+            assert lib().slam_op_gemm_tn(ptr(a), ptr(b), ptr(dW), 0, M, N, K, ptr(ws), stream()) == 0
+            sync()
+            outs.append(dW.clone())
+            check(f"gemm_tn_224 {M}x{N}x{K}", dW, ref, 1e-5, 1e-4)
+            assert lib().slam_op_gemm_tn(ptr(a), ptr(b), ptr(dW), 1, M, N, K, ptr(ws), stream()) == 0
+            sync()
+            check(f"gemm_tn_224 accumulate {M}x{N}x{K}", dW, 2 * ref, 1e-5, 1e-4)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        lib().slam_set_option(None, b"gemm_tn224", 1)
+
+
 # --------------------------------------------------------------------------------------- RMSNorm
 @pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536)])
 def test_rmsnorm_fwd_bwd(M, H):
