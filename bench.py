@@ -15,6 +15,9 @@ Extra objects on the line:
                  launch / mean launch time measured here with HIP events on the launch stream, against the
                  2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md). `step_frac` is the whole-step
                  figure: tokens/s x 2.282 GFLOP/token / peak.
+  hbm_kernels  - the memory-bound kernels (RMSNorm forward / backward, AdamW, gradient norm) timed here: algorithmic bytes /
+                 time against the 8 TB/s HBM peak; `extras` - GA = 16 and the recipe's bf16 optimizer state, measured after
+                 the timed region; config.ms_per_step_median - median of the per-step HIP-event times.
   cpu_baseline - the fp32 CPU oracle (oracle/slam_oracle.py, a port of the reference step: it cannot run the
                  reference's cli/train.py itself) timed on this box's host cores on a bounded
                  sample (B=1, T=1024 fwd+bwd+clip+AdamW, median of 3 steps after a warm-up: 10-15 s of CPU work).
@@ -103,9 +106,100 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
-            # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes): a recorded
-            # measurement of this same kernel and shape (profiles/r1_pmc_gateup_traffic.md), not collected live
-            "traffic": 452.3e6, "algorithmic_bytes": 271.2e6}
+            # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
+            # same kernel and shape: a RECORDED measurement (profiles/r2_pmc_step.md: 213.2 MB read + 239.1 MB written, the
+            # kernel is unchanged since round 1), not collected live - counters need rocprofv3 around the process
+            "traffic": 452.3e6, "traffic_source": "recorded: profiles/r2_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+            "algorithmic_bytes": 271.2e6}
+
+
+PEAK_HBM = 8.0e12  # B/s, MI355X_MICROARCH.md (about 6.3e12 reachable by a streaming copy)
+
+
+def _time_us(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def hbm_kernel_rates(model, trainer):
+    """The memory-bound kernels of the step at the bench shape: algorithmic bytes per launch
+     / mean launch time measured here with HIP events -> GB/s against the 8 TB/s HBM peak. The matching
+    counter-based figures (FETCH_SIZE / WRITE_SIZE per kernel) are in profiles/r2_pmc_step.md."""
+    from slamkit_amd import engine as E
+    lib = E.load_library()
+    st = E.current_stream_ptr()
+    dev = model.device
+    M, H = B * T, 896
+    x = (torch.randn(M, H, device=dev)).to(torch.bfloat16)
+    w = torch.ones(H, dtype=torch.bfloat16, device=dev)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    dw = torch.empty(H, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.slam_op_rmsnorm_bwd_workspace(M, H) // 4 + 16, dtype=torch.float32, device=dev)
+    out = []
+
+    def row(name, us, nbytes, what):
+        out.append({"kernel": name, "us": round(us, 2), "algorithmic_bytes": int(nbytes), "GB_per_s": round(nbytes / us / 1e3, 1),
+                    "frac_of_8TBps": round(nbytes / (us * 1e-6) / PEAK_HBM, 3), "bytes": what})
+
+    us = _time_us(lambda: lib.slam_op_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), M, H, 1e-6, st))
+    row("rmsnorm_fwd_kernel [8192 x 896]", us, 4 * M * H, "4 B/elem: bf16 read + bf16 write")
+    us = _time_us(lambda: lib.slam_op_rmsnorm_bwd(y.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), x.data_ptr(), dx.data_ptr(),
+                                                   dw.data_ptr(), ws.data_ptr(), M, H, st))
+    row("rmsnorm_bwd_kernel [8192 x 896] (+ fused residual-gradient add)", us, 8 * M * H, "8 B/elem: x, dy, dres read + dx written")
+    n = model.engine.n_params
+    eng = model.engine
+    if trainer.state_dtype == torch.float32:
+        us = _time_us(lambda: eng.adamw_step(model.flat_master, trainer.exp_avg, trainer.exp_avg_sq, trainer.norm_out, 0.0, 0.9, 0.999,
+                                             1e-8, 0.0, 1000, zero_grad=False), iters=5, warm=2)
+        # (the launch includes the transposed-weight-image refresh: + 4 B per matrix element)
+        row("adamw_kernel + transpose_bf16_kernel (fp32 master + moments)", us, 34 * n, "30 B/param AdamW + 4 B/param image refresh")
+    us = _time_us(lambda: eng.grad_norm(0.5, trainer.norm_out), iters=10, warm=2)
+    row("sumsq_partial_kernel + norm_finish_kernel (global gradient norm)", us, 4 * n, "4 B/param")
+    return out
+
+
+def extra_measurements(model, trainer, rank, dev, a):
+    """After the timed region (never part of `value`): the same step at GA = 16 (the optimizer and the exposed gradient
+    exchange amortised over 16 micro-batches) and with the recipe's own optimizer precision
+    (bf16 parameters + bf16 Adam moments, /root/reference config/model/slam.yaml:9)."""
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    res = {}
+    world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def run(tr, ga, steps, warm):
+        bt = [[synth_batch(rank, 100 + j, dev) for j in range(ga)]]
+        n_items = float(B * T * ga)
+        for _ in range(warm):
+            tr.optimizer_step(bt[0], 1e-3, counts=(n_items, n_items))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.optimizer_step(bt[0], 1e-3, counts=(n_items, n_items))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"tokens_per_s": round(world * B * T * ga * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
+
+    res["grad_accum_16"] = run(trainer, 16, 3, 1)
+    args2 = SLAMTrainingArguments(per_device_train_batch_size=B, gradient_accumulation_steps=1, learning_rate=1e-3, max_grad_norm=0.5,
+                                  logging_steps=0, optim_state_dtype="bfloat16",
+                                  ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"))
+    if trainer.state_dtype == torch.float32:
+        del trainer.exp_avg, trainer.exp_avg_sq
+        tr2 = SLAMTrainer(model=model, args=args2)  # drops the fp32 master: the bf16 parameters become the only copy
+        res["recipe_optimizer_bf16_state"] = run(tr2, 1, max(5, min(a.steps, 20)), 3)
+    return res
 
 
 def usable_cores() -> int:
@@ -240,6 +334,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the GA=16 and recipe-optimizer measurements after the timed region")
     ap.add_argument("--grad-accum", type=int, default=1)
     ap.add_argument("--workload", default="slam358m", choices=["slam358m", "qwen1p5b"],
                     help="slam358m = BASELINE.json configs[1] (the headline metric); qwen1p5b = configs[3]-shaped extra")
@@ -302,15 +397,20 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step device times (no host sync)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         step(a.warmup + i)
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    ms_median = per_step[len(per_step) // 2]
     loss = float(trainer._loss_acc) / max(1, trainer._loss_n)
     exposed = trainer.reducer.exposed_ms()  # last step: compute-stream stall behind the gradient all-reduce
     if world > 1:
@@ -332,12 +432,17 @@ def main():
                        "optimizer": ("AdamW fp32 master+moments" if args.optim_state_dtype == "float32" else
                                      "AdamW bf16 parameters+moments (the recipe's precision)") + ", clip 0.5",
                        "final_loss": round(loss, 4),
+                       "ms_per_step_median": round(ms_median, 3), "ms_per_step_min": round(per_step[0], 3),
+                       "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
                        "exposed_comm_ms_last_step": round(exposed, 3)},
         }
         roof = dominant_kernel_roofline(model)
         roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
         out["roofline"] = roof
+        out["hbm_kernels"] = hbm_kernel_rates(model, trainer)
+        if not a.no_extras:
+            out["extras"] = extra_measurements(model, trainer, rank, dev, a)
         if world == 1 and not a.no_cpu_baseline:
             del trainer, model
             torch.cuda.empty_cache()

@@ -432,14 +432,23 @@ def test_configs3_full_depth_packed_vs_oracle():
     ids, pos, lab = _packed_row(lens, cfg.vocab, 151667, gen)
     assert ids.shape == (1, sum(lens))
     loss_ref, logits_ref, grads_ref = O.forward_loss_grads(cfg, sd_bf, ids, lab, position_ids=pos, packed=True)
-    del sd_bf
+    # Logit tolerance at this depth and width: the 2e-2 of SURVEY.md §8c was calibrated on shallow models. The reference's
+    # OWN precision (bf16 tensors between modules, oracle `bf16_acts`, pinned on the tiny model against the reference's
+    # bf16-autocast run in tests/test_oracle_golden.py) sits 2.9e-2 away from the fp32 run here (1.8e-2 for Slam-358M): the
+    # engine has to be at least as close to fp32 as that path is (+10 % slack), and never needs to beat 2e-2.
+    with torch.no_grad():
+        emu = O.model_forward(cfg, sd_bf, ids, position_ids=pos, packed=True, bf16_acts=True)
+    emu_dev = rel_err(emu, logits_ref)
+    del sd_bf, emu
     m.zero_grad()
     out = m(input_ids=ids, position_ids=pos, labels=lab)
     m.backward()
     torch.cuda.synchronize()
     print("configs[3] full-depth loss engine/oracle", float(out.loss), float(loss_ref))
     assert abs(float(out.loss) - float(loss_ref)) <= 2e-2
-    check("configs[3] logits", out.logits.float().cpu(), logits_ref, 2e-2)
+    tol = max(2e-2, 1.1 * emu_dev)
+    print(f"[parity] configs[3] bf16-path emulation vs fp32: logits rel-rms {emu_dev:.3e} -> engine tolerance {tol:.3e}")
+    check("configs[3] logits", out.logits.float().cpu(), logits_ref, tol)
     del logits_ref
     assert len(list(m.named_grads())) == 338
     _check_all_grads(m, grads_ref, "configs[3] 28 L, V 152167, packed 2048")

@@ -202,3 +202,22 @@ def test_adamw_bf16_state_matches_torch_fused():
         # one bf16 ulp, or a near-exact cancellation that torch's fma keeps as a 1e-11-sized residue
         tol = 2.0 ** -7 * ref.float().abs() + 1e-6 * float(ref.float().abs().max())
         assert bool(((mine.float() - ref.float()).abs() <= tol).all())
+
+
+def test_bf16_activation_emulation_matches_reference_autocast_noise(golden_npz, golden_data):
+    """oracle `bf16_acts` (bf16 tensors between modules, fp32 inside) restates the reference's own bf16 precision: on the
+    tiny model its distance from the fp32 logits must be the distance the REAL reference measured for its bf16-autocast
+    run (golden `pad_logits_bf16_rmsrel`, tests/golden/make_golden.py G5), within 25 %. The deep-model GPU tests use it
+    to state how far a bf16 implementation may sit from the fp32 oracle."""
+    meta = golden_data["meta"]
+    cfg = O.OracleConfig(**meta["config"])
+    sd = O.init_weights(cfg, seed=meta["seed"], bias_std=meta["bias_std"], norm_jitter=meta["norm_jitter"])
+    sdb = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    ids, am = torch.from_numpy(golden_npz["pad_ids"]), torch.from_numpy(golden_npz["pad_mask"])
+    with torch.no_grad():
+        a = O.model_forward(cfg, sd, ids, attention_mask=am)
+        b = O.model_forward(cfg, sdb, ids, attention_mask=am, bf16_acts=True)
+    m = am.bool()
+    dev = float((b[m] - a[m]).pow(2).mean().sqrt() / a[m].pow(2).mean().sqrt())
+    ref = float(golden_npz["pad_logits_bf16_rmsrel"])
+    assert 0.75 * ref <= dev <= 1.25 * ref, (dev, ref)
