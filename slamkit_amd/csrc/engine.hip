@@ -362,8 +362,6 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256_dswiglu")) { gemm_set_256_dswiglu((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256_stagger")) { gemm_set_256_stagger((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256_stagger_groups")) { gemm_set_256_stagger_groups((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224")) { gemm_set_tn224((int)value); return SLAM_OK; }

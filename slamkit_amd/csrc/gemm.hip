@@ -56,7 +56,6 @@ struct GemmArgs {
   int rope_heads;
   int group_rows;  // tile rasterisation group height (0/1 = plain row-major)
   int nt_store;    // streaming (non-temporal) output stores: large outputs must not evict the operand panels from L2
-  int stagger, stagger_groups;  // 256 x 256 kernel: first-round blocks of group k start k * stagger * 8128 cycles late
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -636,7 +635,9 @@ SLAM_DEVICE void wait_ph(int which) {
 }
 SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// (measured against this schedule in round 1: one barrier per phase without the stagger +3 % time, no priority raise +8 %)
+// (measured against this schedule: one barrier per phase without the wave-row stagger +3 % time, no priority raise +8 %;
+//  round 2: starting groups of first-round blocks a fraction of a tile period late, to de-synchronise the epilogue store
+//  bursts of the 256 resident blocks, moves the fused gate|up launch by <= 4 % in isolation and the step by nothing)
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
@@ -664,14 +665,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   const int nk = p.Kc / BK;
   const uint32_t lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  // De-synchronised first round: every tile of a launch takes the same time, so the 256 resident blocks reach their
-  // epilogues together and their output stores (192 KB per block with the fused SwiGLU: 49 MB per round, more than the
-  // 32 MB of L2) drain at HBM speed while every MFMA pipe idles. Groups of first-round blocks start a fraction of a tile
-  // period late; the rounds stay out of phase from then on.
-  if (p.stagger > 0 && (int)blockIdx.x < 256) {
-    const int grp = ((int)blockIdx.x >> 3) % p.stagger_groups;
-    for (int i = 0; i < grp * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // DMA source offsets, 2 chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
   uint32_t vo[4][2];
 #pragma unroll
@@ -1251,9 +1244,6 @@ static bool use_256(const GemmArgs& a) {
 // per CU, so that one block's HBM-bound epilogue sits beside another block's - or a concurrent wgrad's - MFMA loop)
 static int g_gemm_256_dswiglu = 1;
 void gemm_set_256_dswiglu(int on) { g_gemm_256_dswiglu = on; }
-static int g_256_stagger = 0, g_256_stagger_groups = 2;
-void gemm_set_256_stagger(int v) { g_256_stagger = v; }
-void gemm_set_256_stagger_groups(int v) { g_256_stagger_groups = v; }
 static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
 void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
 static int launch_256(GemmArgs a, hipStream_t st) {
@@ -1267,8 +1257,6 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.tiles_c = a.Cn / 256;
   a.group_rows = g_group_rows_256;
   a.nt_store = g_nt_store;
-  a.stagger = g_256_stagger;
-  a.stagger_groups = g_256_stagger_groups > 0 ? g_256_stagger_groups : 2;
   gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }

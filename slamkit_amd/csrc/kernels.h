@@ -16,8 +16,6 @@ void gemm_set_group_rows(int g);
 void gemm_set_nt_store(int on);
 void gemm_set_256(int on);
 void gemm_set_256_dswiglu(int on);
-void gemm_set_256_stagger(int v);
-void gemm_set_256_stagger_groups(int v);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
 void gemm_set_tn224(int v);
