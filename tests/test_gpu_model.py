@@ -477,4 +477,4 @@ def test_configs3_full_depth_packed_vs_oracle():
     assert math.isfinite(l0) and abs(l0 - math.log(cfg.vocab)) < 0.5
     assert l0 == l1 and torch.equal(g0, g1)  # no atomics anywhere: the same bits every run
     l2, g2 = run([3, 0, 11, 7, 1, 9, 2, 10, 5, 4, 8, 6])
-    assert abs(l2 - l0) <= 1e-5 and rel_err(g2, g0) <= 2e-3
+    assert abs(l2 - l0) <= 1e-4 and rel_err(g2, g0) <= 2e-3  # fp32 summation order of 16,384 row losses / of the wgrad contraction
