@@ -140,8 +140,11 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
 
 /* ---- tuning knobs ---------------------------------------------------------------------------*/
 /* Tuning / mode switches. "grad_overwrite_next" = 1: the next slam_backward stores the gradients instead of adding to
- * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "overlap_adamw",
- * "fuse_swiglu", "fuse_dswiglu" and the "gemm_*" keys select measured kernel variants. */
+ * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "bwd_wgrad_stream" (default
+ * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
+ * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
+ * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
+ * "gemm_256_dswiglu", "gemm_tn224", "gemm_tn_balanced", "gemm_group_rows" select kernels. */
 int slam_set_option(SlamEngine* h, const char* key, int64_t value);
 
 /* ---- single-op entry points (parity tests call each kernel through the ABI) -------------------*/

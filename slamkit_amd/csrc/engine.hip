@@ -253,7 +253,7 @@ int join_optimizer(SlamEngine* h, hipStream_t st) {
 
 extern "C" {
 
-const char* slam_version(void) { return "slam-engine gfx950 r1"; }
+const char* slam_version(void) { return "slam-engine gfx950 r2"; }
 
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
