@@ -1,0 +1,30 @@
+"""Three optimizer steps of the bench workload and nothing else (no timing events, no probes): the process that
+tools/pmc_step.sh wraps in rocprofv3 --pmc. Usage: python tools/one_step.py [slam358m|qwen1p5b]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from slamkit_amd.model import UnitLM, UnitLMConfig  # noqa: E402
+from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "slam358m"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+if wl == "slam358m":
+    model = UnitLM(UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=bench.V, max_tokens=bench.B * bench.T), seed=0)
+    tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=bench.B, learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0))
+    n = float(bench.B * bench.T)
+    for i in range(3):
+        tr.optimizer_step([bench.synth_batch(0, i, dev)], 1e-3, counts=(n, n))
+else:
+    model = UnitLM(UnitLMConfig(base_model_name=bench.W4["name"], vocab_size=bench.W4["vocab"], max_tokens=bench.W4["tokens"]), seed=0)
+    tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=1, learning_rate=5e-4, max_grad_norm=0.5, logging_steps=0))
+    for i in range(3):
+        mb, _ = bench.synth_packed_batch(0, i, dev)
+        c = float((mb["labels"] != -100).sum())
+        tr.optimizer_step([mb], 5e-4, counts=(c, c))
+torch.cuda.synchronize()
+print("done", float(tr._loss_acc) / max(1, tr._loss_n))
