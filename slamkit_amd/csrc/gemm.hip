@@ -136,8 +136,9 @@ SLAM_DEVICE void store_transposed(char* tile, int u, const uint4* rin, uint32_t 
 //      LDS at M0 + lane*16; issued from asm so the compiler's waitcnt insertion does not see it
 //      (we count it ourselves with s_waitcnt vmcnt(N)). Rows past the end are clamped: their
 //      products only reach output rows that are never stored. ---------------------------------
-// Per-lane byte offsets (tile-invariant) of the 4 chunks a lane moves; the K-loop only advances the
-// wave-uniform base pointer G + k0.
+// Per-lane byte offsets (tile-invariant) of the 4 chunks a lane moves, RELATIVE to the tile's first row (a 32-bit
+// offset from the matrix origin wraps once rows x ld x 2 B passes 4 GB: dlogits [16384][152320] is 4.99 GB); the K-loop
+// only advances the wave-uniform 64-bit base pointer G + row0 * ld + k0.
 template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* voff) {
 #pragma unroll
@@ -146,7 +147,7 @@ SLAM_DEVICE void glds_offsets(int ld, int nrows, int row0, int tid, uint32_t* vo
     int row = P >> 3, cs = P & 7;
     int c = cs ^ lds_swz_key(row);
     int gr = row0 + row;
-    gr = gr < nrows ? gr : nrows - 1;
+    gr = (gr < nrows ? gr : nrows - 1) - row0;  // relative to the tile's first row: the 32-bit offset must not span the matrix
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
@@ -166,7 +167,7 @@ SLAM_DEVICE void glds_offsets_perm(int ld, int nrows, int row0, int tid, uint32_
     int row = P >> 3, cs = P & 7;
     int c = cs ^ lds_swz_key(row);
     int gr = row0 + (row & ~63) + perm64(row & 63);
-    gr = gr < nrows ? gr : nrows - 1;
+    gr = (gr < nrows ? gr : nrows - 1) - row0;
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
@@ -425,8 +426,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const uint32_t st = lds0 + (uint32_t)((t % NSTAGE) * STAGE);
       // wave-uniform bases: direct operands advance along the contiguous contraction dim, transposed
       // operands by whole rows
-      const bf16_t* ga = TR ? p.A + (size_t)k0 * p.lda : p.A + k0;
-      const bf16_t* gb = TR ? p.B + (size_t)k0 * p.ldb : p.B + k0;
+      const bf16_t* ga = TR ? p.A + (size_t)k0 * p.lda : p.A + (size_t)row0 * p.lda + k0;
+      const bf16_t* gb = TR ? p.B + (size_t)k0 * p.ldb : p.B + (size_t)col0 * p.ldb + k0;
       glds_tile<THREADS, BMT>(ga, voa, wv, st);
       glds_tile<THREADS, BN>(gb, vob, wv, st + A_BYTES);
     };
@@ -672,14 +673,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     const int P = i * 512 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int grow = row0 + (r >> 6) * 128 + h * 64 + (r & 63);
-      const int gcol = col0 + (r >> 5) * 64 + perm64(h * 32 + (r & 31));
+      const int grow = (r >> 6) * 128 + h * 64 + (r & 63);          // relative to the tile origin: 32-bit offsets must not
+      const int gcol = (r >> 5) * 64 + perm64(h * 32 + (r & 31));   // span the matrix (dlogits [16384][152320] is 4.99 GB)
       vo[h ? 3 : 0][i] = (uint32_t)(((size_t)grow * p.lda + c * 8) * sizeof(bf16_t));
       vo[1 + h][i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
     }
   }
   auto issue_half = [&](int h, int t) {  // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1)
-    const bf16_t* base = ((h == 0 || h == 3) ? p.A : p.B) + (size_t)t * BK;
+    const bf16_t* base = ((h == 0 || h == 3) ? p.A + (size_t)row0 * p.lda : p.B + (size_t)col0 * p.ldb) + (size_t)t * BK;
     const uint32_t dst = lds0 + (uint32_t)((t & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));

@@ -59,6 +59,32 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
 
 
+def test_gemm_nt_operand_beyond_4GB():
+    """A row operand of more than 4 GB (the d-logits of the configs[3] micro-batch: [16384][152320] bf16 = 4.99 GB): the
+    per-lane 32-bit DMA offsets are relative to the tile, the 64-bit part rides in the wave-uniform base. Regression for a
+    round-1 bug (offsets from the matrix origin wrapped for rows >= 14,099; found by the segment-permutation property of
+    test_configs3_full_depth_packed_vs_oracle). Both NT kernels; the last and the first rows against an fp32 reference."""
+    M, N, K = 16384, 1024, 152320
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    for r in range(0, M, 2048):
+        X[r:r + 2048] = (torch.randn(2048, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    assert X.numel() * 2 > 2 ** 32
+    Wf = W.float().cpu()
+    try:
+        for mode in (0, 2):  # 128 x 128 kernel, 256 x 256 kernel
+            assert lib().slam_set_option(None, b"gemm_256", mode) == 0
+            Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert lib().slam_op_gemm_nt(ptr(X), ptr(W), ptr(Y), None, None, M, N, K, 1, stream()) == 0
+            sync()
+            for lo in (0, 14080, M - 128):
+                ref = X[lo:lo + 128].float().cpu() @ Wf.t()
+                check(f"gemm_nt >4GB rows {lo}.. gemm_256={mode}", Y[lo:lo + 128].float(), ref, 4e-3, 2e-2)
+    finally:
+        lib().slam_set_option(None, b"gemm_256", 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 192, 384), (300, 512, 256), (1000, 1152, 896),
                                    (74, 1024, 256)])
 def test_gemm_nn(M, N, K):
