@@ -365,6 +365,11 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224")) { gemm_set_tn224((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn224_min_m")) { gemm_set_tn224_min_m((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn224_max_split")) { gemm_set_tn224_max_split((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn_bal_bg_max_split")) { gemm_set_tn_bal_bg_max_split((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn224_bg_min_m")) { gemm_set_tn224_bg_min_m((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_tn224_bg_max_split")) { gemm_set_tn224_bg_max_split((int)value); return SLAM_OK; }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
@@ -487,7 +492,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   auto wait_side = [&](int layer, int k) -> int { return two ? (int)hipStreamWaitEvent(st, ev(layer, k), 0) : 0; };
 
   CK(fork(L, 0));
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, ws));
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, ws, two ? 1 : 0));
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
@@ -501,7 +506,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     LayerAct& a = h->la[l];
     // MLP
     CK(fork(l, 0));
-    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, ws));
+    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, ws, two ? 1 : 0));
     CK(mark(l, 4));  // dh has been read by the wgrad
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
@@ -510,13 +515,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
     CK(fork(l, 1));
-    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, ws));
+    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, ws, two ? 1 : 0));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     if (l + 1 < L) CK(wait_side(l + 1, 5));  // the previous layer's wo wgrad still reads dh2
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
     CK(fork(l, 2));
-    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, ws));
+    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, ws, two ? 1 : 0));
     CK(mark(l, 5));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
@@ -524,7 +529,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
                 nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
     CK(fork(l, 3));
-    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, ws));
+    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, ws, two ? 1 : 0));
     CK(mark(l, 6));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
     CK(wait_side(l, 4));  // this layer's wd wgrad still reads dh
@@ -553,7 +558,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   CK(fork(L, 1));
   if (VP == VPAD_SMALL) {
     CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
-    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, ws));
+    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, ws, two ? 1 : 0));
   } else {
     CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
   }

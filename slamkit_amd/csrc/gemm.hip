@@ -1343,14 +1343,16 @@ struct BalPlan { int T_A, S_A, per_A, SA_act, T_B, S_B, per_B, SB_act; };
 static bool tn_bal_ok(int M, int N, int K) {
   return g_tn_balanced && g_gemm_tn_dma == 1 && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
 }
-static BalPlan tn_bal_plan(int M, int N, int K) {
+static int g_bal_bg_max_split = 4;  // background launches of the 128 x 128 balanced kernel: limit on pieces per tile (measured on the Slam-358M step: 1 -> 291.7k, 2 -> 306.4k, 3 -> 312.2k, 4 -> 312.4k, 5 -> 311.3k, 6 -> 310.6k, 8 -> 308.7k tok/s)
+void gemm_set_tn_bal_bg_max_split(int v) { g_bal_bg_max_split = v < 1 ? 1 : v > 8 ? 8 : v; }
+static BalPlan tn_bal_plan(int M, int N, int K, int max_split = 8) {
   const int T = (N / BM) * (K / BN), KS = M / BK;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   const int OVH = 3;  // K-steps' worth of prologue + epilogue per piece (estimate used to choose between plans)
   BalPlan best{};
   int best_cost = 1 << 30;
   auto consider = [&](int S, int T_A) {
-    if (S < 1 || S > 8 || S > KS || T_A < 0 || T_A > T) return;
+    if (S < 1 || S > max_split || S > KS || T_A < 0 || T_A > T) return;
     BalPlan pl{};
     pl.T_A = T_A; pl.S_A = S; pl.per_A = cdiv(KS, S); pl.SA_act = T_A ? cdiv(KS, pl.per_A) : 0;
     pl.T_B = T - T_A;
@@ -1358,6 +1360,7 @@ static BalPlan tn_bal_plan(int M, int N, int K) {
     if (pl.T_B) {
       int sb = BAL_SLOTS / pl.T_B;
       if (sb > 16) sb = 16;
+      if (sb > 2 * max_split) sb = 2 * max_split;
       if (sb < 1) sb = 1;
       if (sb > KS) sb = KS;
       pl.S_B = sb; pl.per_B = cdiv(KS, sb); pl.SB_act = cdiv(KS, pl.per_B);
@@ -1368,11 +1371,11 @@ static BalPlan tn_bal_plan(int M, int N, int K) {
     cost += (int)(0.5 * slab_mb);
     if (cost < best_cost) { best_cost = cost; best = pl; }
   };
-  for (int S = 1; S <= 8; ++S) {
+  for (int S = 1; S <= max_split; ++S) {
     consider(S, T);                                                  // everything in equal pieces
     int full = (T * S / BAL_SLOTS) * BAL_SLOTS / S;                  // tiles that make whole rounds
     if (S > 1) full &= ~7;
-    if (full > 0 && full < T) consider(S, full);
+    if (full > 0 && full < T && max_split > 1) consider(S, full);
   }
   return best;
 }
@@ -1380,10 +1383,21 @@ static BalPlan tn_bal_plan(int M, int N, int K) {
 // ---- 256 x 224 phase-scheduled wgrad: shape test, balanced plan, launch -------------------------------------------------
 // tn224: 0 = off, 1 = when the plan fills the chip (default), 2 = whenever the shape allows (tests)
 static int g_tn224 = 1;
+static int g_tn224_min_m = 16384, g_tn224_max_split = 16;
+// "background" launches (the engine's wgrad side stream: other kernels fill whatever CUs a launch leaves free, so what
+// counts is CU-time per flop, not chip fill): no K-splitting at all - one block per tile walks the whole contraction (no
+// slabs, no reduce pass, 128 K-steps of main loop per 229 KB epilogue), from much shorter contractions on.
+// Measured on the Slam-358M step (same box, twice): 304.6k tok/s vs 292.5k with the balanced 128 x 128 kernel on that
+// stream (+4.1 %); limits of 2 / 3 / 16 pieces: 299.0k / 288.1k / 289.4k.
+static int g_tn224_bg_min_m = 4096, g_tn224_bg_max_split = 1;
 void gemm_set_tn224(int v) { g_tn224 = v; }
+void gemm_set_tn224_min_m(int v) { g_tn224_min_m = v; }
+void gemm_set_tn224_max_split(int v) { g_tn224_max_split = v < 1 ? 1 : v > 16 ? 16 : v; }
+void gemm_set_tn224_bg_min_m(int v) { g_tn224_bg_min_m = v; }
+void gemm_set_tn224_bg_max_split(int v) { g_tn224_bg_max_split = v < 1 ? 1 : v > 16 ? 16 : v; }
 struct Plan224 { int T_A, S_A, per_A, T_B, S_B, per_B, slabs; bool tr; int tiles_a, tiles_b; };
 // orientation: 0 = none, 1 = dW[n][k] with n on the 256 side (N % 256 == 0, K % 224 == 0), 2 = transposed store (k on the 256 side)
-static int tn224_orient(int M, int N, int K) {
+static int tn224_orient(int M, int N, int K, int background = 0) {
   if (!g_tn224 || (M % BK)) return 0;
   const bool o1 = (N % 256 == 0) && (K % 224 == 0), o2 = (K % 256 == 0) && (N % 224 == 0);
   if (!o1 && !o2) return 0;
@@ -1392,25 +1406,26 @@ static int tn224_orient(int M, int N, int K) {
   // contraction, but at M = 8192 every piece is 13..64 K-steps long and the one-block-per-CU epilogue (229 KB of fp32 per
   // piece, nothing to overlap it with) plus the slab pass give the gain back: gate|up weight 148-157 us vs 149-153,
   // down weight 77 vs 86 us, Slam-358M step 291.1k vs 294.3k tok/s. Default: contractions of 16,384 tokens and more.
-  if (g_tn224 != 2 && (tiles < 64 || M < 16384)) return 0;
+  if (g_tn224 != 2 && (background ? (tiles < 32 || M < g_tn224_bg_min_m) : (tiles < 64 || M < g_tn224_min_m))) return 0;
   return o1 ? 1 : 2;
 }
-static Plan224 tn224_plan(int M, int N, int K, int orient) {
+static Plan224 tn224_plan(int M, int N, int K, int orient, int max_split = -1) {
   Plan224 best{};
+  if (max_split < 1) max_split = g_tn224_max_split;
   const int SLOTS = 256;  // one block per CU
   const int T = (N / (orient == 1 ? 256 : 224)) * (K / (orient == 1 ? 224 : 256)), KS = M / BK;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   const int OVH = 3;  // K-steps' worth of prologue + epilogue per piece
   int best_cost = 1 << 30;
   auto consider = [&](int S, int T_A) {
-    if (S < 1 || S > 16 || S > KS || T_A < 0 || T_A > T) return;
+    if (S < 1 || S > max_split || S > KS || T_A < 0 || T_A > T) return;
     Plan224 pl{};
     pl.T_A = T_A; pl.per_A = cdiv(KS, S); pl.S_A = T_A ? cdiv(KS, pl.per_A) : 1;
     pl.T_B = T - T_A; pl.S_B = 1; pl.per_B = KS;
     int cost = T_A ? cdiv(T_A * pl.S_A, SLOTS) * (pl.per_A + OVH) : 0;
     if (pl.T_B) {
       int sb = SLOTS / pl.T_B;
-      if (sb > 16) sb = 16;
+      if (sb > max_split) sb = max_split;
       if (sb < 1) sb = 1;
       if (sb > KS) sb = KS;
       pl.per_B = cdiv(KS, sb); pl.S_B = cdiv(KS, pl.per_B);
@@ -1421,7 +1436,7 @@ static Plan224 tn224_plan(int M, int N, int K, int orient) {
     cost += (int)(0.12 * pl.slabs * (256 * 224 * 4) / 1e6);
     if (cost < best_cost) { best_cost = cost; best = pl; }
   };
-  for (int S = 1; S <= 16; ++S) {
+  for (int S = 1; S <= max_split; ++S) {
     consider(S, T);
     const int full = (T * S / SLOTS) * SLOTS / S;
     if (full > 0 && full < T) consider(S, full);
@@ -1432,16 +1447,18 @@ static Plan224 tn224_plan(int M, int N, int K, int orient) {
   return best;
 }
 static size_t tn224_workspace_bytes(int M, int N, int K) {
-  const int o = tn224_orient(M, N, K) ? tn224_orient(M, N, K) : 0;
-  // sized as if forced (g_tn224 == 2 may be switched on later by a test): any eligible shape reserves its slabs
+  // sized for every setting the options can take later (forced on, any split limit): any eligible shape reserves its slabs
   const bool o1 = (M % BK == 0) && (N % 256 == 0) && (K % 224 == 0), o2 = (M % BK == 0) && (K % 256 == 0) && (N % 224 == 0);
-  (void)o;
   if (!o1 && !o2) return 0;
-  const Plan224 pl = tn224_plan(M, N, K, o1 ? 1 : 2);
-  return (size_t)pl.slabs * 256 * 224 * sizeof(float);
+  int slabs = 0;
+  for (int ms = 1; ms <= 16; ++ms) {
+    const Plan224 pl = tn224_plan(M, N, K, o1 ? 1 : 2, ms);
+    if (pl.slabs > slabs) slabs = pl.slabs;
+  }
+  return (size_t)slabs * 256 * 224 * sizeof(float);
 }
 static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-                        float* ws, int orient, hipStream_t st) {
+                        float* ws, int orient, int background, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
@@ -1449,7 +1466,7 @@ static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumu
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const Plan224 pl = tn224_plan(M, N, K, orient);
+  const Plan224 pl = tn224_plan(M, N, K, orient, background ? g_tn224_bg_max_split : g_tn224_max_split);
   Tn224Args a{};
   a.A = orient == 1 ? dY : X; a.lda = orient == 1 ? ldy : ldx;
   a.B = orient == 1 ? X : dY; a.ldb = orient == 1 ? ldx : ldy;
@@ -1484,9 +1501,10 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K) {
 
 // dW[N,K] (fp32) (+)= dY[M,N]^T X[M,K]; contraction over M; split-K partials in `ws`.
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
-            int ldx, float* ws, hipStream_t st) {
+            int ldx, float* ws, hipStream_t st, int background) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
-  if (const int orient = tn224_orient(M, N, K)) return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, st);
+  if (const int orient = tn224_orient(M, N, K, background))
+    return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st);
   if (tn_bal_ok(M, N, K)) {
     static bool attr = false;
     if (!attr) {
@@ -1495,7 +1513,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
       if (e != hipSuccess) return (int)e;
       attr = true;
     }
-    const BalPlan pl = tn_bal_plan(M, N, K);
+    const BalPlan pl = tn_bal_plan(M, N, K, background ? g_bal_bg_max_split : 8);
     BalArgs a{};
     a.A = dY; a.B = X; a.dW = dW; a.lda = ldy; a.ldb = ldx; a.ldc = K;
     a.tiles_r = N / BM; a.tiles_c = K / BN; a.KS = M / BK; a.group_rows = g_group_rows;

@@ -19,6 +19,11 @@ void gemm_set_256_dswiglu(int on);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
 void gemm_set_tn224(int v);
+void gemm_set_tn224_min_m(int v);
+void gemm_set_tn224_max_split(int v);
+void gemm_set_tn_bal_bg_max_split(int v);
+void gemm_set_tn224_bg_min_m(int v);
+void gemm_set_tn224_bg_max_split(int v);
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
@@ -30,8 +35,10 @@ int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, 
             hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
+// background = 1: the launch shares the GPU with other streams (the engine's wgrad side stream): plans for CU-time per
+// flop instead of chip fill (no K-splitting on the 256 x 224 kernel)
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-            float* ws, hipStream_t st);
+            float* ws, hipStream_t st, int background = 0);
 
 // attention.hip
 size_t attn_plan_ints(int M);
