@@ -361,6 +361,8 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_nt224")) { gemm_set_nt224((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_nt224_min_k")) { gemm_set_nt224_min_k((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256_dswiglu")) { gemm_set_256_dswiglu((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
@@ -480,6 +482,10 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // k 0..3 main->side "operands ready" (wd, wgu, wo, wqkv), k 4..6 side->main "done reading" (dh, dh2, dqkv)
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
+  struct SharedGuard {  // dgrad launches of this call may plan for a GPU they share with the wgrad stream
+    explicit SharedGuard(int on) { gemm_set_shared(on); }
+    ~SharedGuard() { gemm_set_shared(0); }
+  } shared_guard(two ? 1 : 0);
   hipStream_t ws = two ? h->wside : st;
   auto ev = [&](int layer, int k) { return h->ev_w[(size_t)layer * 8 + k]; };
   auto fork = [&](int layer, int k) -> int {  // side stream continues after everything enqueued on main so far

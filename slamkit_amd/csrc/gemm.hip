@@ -937,6 +937,168 @@ __global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actua
 }
 
 
+
+// ---- NT GEMM on 256 x 224 tiles, 8 waves, 8-phase schedule (dgrad launches with N = 896 under the two-stream backward) ------
+// C[M][N] = A[M][K] B[N][K]^T (bf16 out, optional residual) with the tile geometry of gemm_tn_224_kernel and the operand
+// staging of gemm_nt_256_kernel: half-tile images [128 rows][64 k] (16-B chunk swizzle, ds_read_b128 fragments),
+//   H0 = A rows {first 32 of each wave row} | H1 = B rows {first 64 of each wave column}
+//   H2 = B rows {last 48 of each wave column} (96 of 128 image rows used) | H3 = A rows {other 32 of each wave row}
+// (operand rows are contraction-contiguous here, so any row selection is a whole 128-B line per row and K-tile).
+// One block per tile, no K-splitting: 8192 x 896 outputs are 128 tiles - half the CUs. That is the point: in backward
+// the wgrad stream keeps the other CUs busy, so a launch should minimise CU-time per flop (1.2-1.4 PFLOP/s-equivalent per
+// occupied CU in the main loop against ~1.0 for the 128 x 128 kernel) rather than fill the chip by itself.
+__global__ __launch_bounds__(512, 1) void gemm_nt_224_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int KT = 4 * HT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave & 3, wc = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tr_ = nid / p.tiles_c, tc_ = nid - tr_ * p.tiles_c;  // the column tiles of a row panel sit on one XCD
+  const int row0 = tr_ * 256, col0 = tc_ * 224;
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t vo[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int P = i * 512 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
+    const int ra0 = (r >> 5) * 64 + (r & 31), ra1 = ra0 + 32;
+    const int rb0 = (r >> 6) * 112 + (r & 63);
+    const int r1 = r < 96 ? r : 95;  // image rows 96..127 of H2 are unused: they repeat the last row
+    const int rb1 = (r1 / 48) * 112 + 64 + (r1 % 48);
+    vo[0][i] = (uint32_t)(((size_t)ra0 * p.lda + c * 8) * sizeof(bf16_t));
+    vo[3][i] = (uint32_t)(((size_t)ra1 * p.lda + c * 8) * sizeof(bf16_t));
+    vo[1][i] = (uint32_t)(((size_t)rb0 * p.ldb + c * 8) * sizeof(bf16_t));
+    vo[2][i] = (uint32_t)(((size_t)rb1 * p.ldb + c * 8) * sizeof(bf16_t));
+  }
+  const bf16_t* Ab = p.A + (size_t)row0 * p.lda;
+  const bf16_t* Bb = p.B + (size_t)col0 * p.ldb;
+  auto issue_half = [&](int h, int t) {
+    const bf16_t* base = ((h == 0 || h == 3) ? Ab : Bb) + (size_t)t * BK;
+    const uint32_t dst = lds0 + (uint32_t)((t & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
+  };
+  f32x4_t acc[4][7];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ka = (l15 >> 1) & 7;
+  auto frag = [&](const char* img, int Pb, int kk) -> uint4 {  // 16-row block Pb of a half-tile image, K-half kk
+    return *reinterpret_cast<const uint4*>(img + (Pb * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ Pb) & 7) << 4));
+  };
+  uint4 afr[2][2], bg0[2][4], bg1[2][3];
+  auto read_A = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) afr[kk][f] = frag(img, wr * 2 + f, kk);
+  };
+  auto read_B0 = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) bg0[kk][f] = frag(img, wc * 4 + f, kk);
+  };
+  auto read_B1 = [&](const char* img) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) bg1[kk][f] = frag(img, wc * 3 + f, kk);
+  };
+  auto mma0 = [&](int ah) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[ah * 2 + fm][fn] = mfma16(bg0[kk][fn], afr[kk][fm], acc[ah * 2 + fm][fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma1 = [&](int ah) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 3; ++fn) acc[ah * 2 + fm][4 + fn] = mfma16(bg1[kk][fn], afr[kk][fm], acc[ah * 2 + fm][4 + fn]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](int t, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const char* buf = smem + (t & 1) * KT;
+    if (!LAST) issue_half(0, t + 1);
+    read_A(buf);
+    read_B0(buf + HT);
+    wait_ph<LAST>(0);
+    raw_barrier();
+    mma0(0);
+    raw_barrier();
+    if (!LAST) issue_half(1, t + 1);
+    read_B1(buf + 2 * HT);
+    wait_ph<LAST>(1);
+    raw_barrier();
+    mma1(0);
+    raw_barrier();
+    if (!LAST) issue_half(2, t + 1);
+    read_A(buf + 3 * HT);
+    raw_barrier();
+    mma1(1);
+    raw_barrier();
+    if (!LAST) issue_half(3, t + 1);
+    wait_ph<LAST>(2);
+    raw_barrier();
+    mma0(1);
+    raw_barrier();
+  };
+  issue_half(0, 0);
+  issue_half(1, 0);
+  issue_half(2, 0);
+  issue_half(3, 0);
+  wait_vmcnt<4>();
+  raw_barrier();
+  if (wc == 1) raw_barrier();
+  for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
+  ktile(nk - 1, std::true_type{});
+  if (wc == 0) raw_barrier();
+
+  // epilogue: lane holds C[m][n .. n+3] per fragment (8-byte stores; optional residual)
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + wr * 64 + fm * 16 + l15;
+    const size_t rowoff = (size_t)m * p.ldc;
+    uint2 rr[7];
+    if (p.resid) {
+#pragma unroll
+      for (int fn = 0; fn < 7; ++fn)
+        rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wc * 112 + fn * 16 + g * 4);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 7; ++fn) {
+      f32x4_t v = acc[fm][fn];
+      if (p.resid) {
+        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
+        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + wc * 112 + fn * 16 + g * 4) = o;
+    }
+  }
+}
+
 // ---- wgrad on 256 x 224 tiles, 8 waves, 8-phase schedule ----------------------------------------------------------------
 // The two big weight gradients of a layer (gate|up: [9728][896], down: [896][4864]; contraction over the M = 8192 tokens)
 // hold 88 % of the wgrad flops and ran at ~930 TFLOP/s on the 128 x 128 one-barrier kernel. Every big matrix of the model
@@ -1261,8 +1423,35 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
+
+// 256 x 224 NT kernel: only in "shared" mode (the engine's two-stream backward), plain or residual epilogue
+static int g_shared = 0;      // set by the engine around slam_backward when the wgrad stream is on
+static int g_nt224 = 1;       // 0 = off, 1 = in shared mode (default), 2 = whenever the shape allows (tests)
+static int g_nt224_min_k = 2048;  // long contractions only (gate|up dgrad, K = 9728): interleaved A/B x3 on the Slam-358M step 311.5-312.0k vs 310.3-310.6k tok/s; with the K = 896 / 1152 dgrads as well: no gain
+void gemm_set_shared(int on) { g_shared = on; }
+void gemm_set_nt224(int v) { g_nt224 = v; }
+void gemm_set_nt224_min_k(int v) { g_nt224_min_k = v; }
+static bool use_nt224(const GemmArgs& a) {
+  if (!g_nt224 || (a.R % 256) || (a.Cn % 224) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
+  if (a.bias || a.act || a.gu || a.rope_cos) return false;
+  if (g_nt224 == 2) return true;
+  return g_shared && a.Kc >= g_nt224_min_k && (a.R / 256) * (a.Cn / 224) >= 64;
+}
+static int launch_nt224(GemmArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_224_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.tiles_r = a.R / 256;
+  a.tiles_c = a.Cn / 224;
+  gemm_nt_224_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  return (int)hipGetLastError();
+}
 // NT launches whose rows / contraction are whole tiles: 256 x 256 8-phase kernel or the 128 x 128 DMA kernel
 static int launch_nt_dma(const GemmArgs& a, hipStream_t st) {
+  if (use_nt224(a)) return launch_nt224(a, st);
   if (use_256(a)) return launch_256(a, st);
   return launch<false, false, false, true, true>(a, 1, st);
 }

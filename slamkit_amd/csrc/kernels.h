@@ -15,6 +15,9 @@ void gemm_set_tn_splits(int s);
 void gemm_set_group_rows(int g);
 void gemm_set_nt_store(int on);
 void gemm_set_256(int on);
+void gemm_set_shared(int on);
+void gemm_set_nt224(int v);
+void gemm_set_nt224_min_k(int v);
 void gemm_set_256_dswiglu(int on);
 void gemm_set_group_rows_256(int g);
 void gemm_set_tn_balanced(int on);
