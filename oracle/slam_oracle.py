@@ -254,7 +254,7 @@ def log_likelihood(cfg, sd, tokens: torch.Tensor, mean_nll: bool, ignore_tokens=
 
 
 def forward_loss_grads(cfg, sd, input_ids, labels, attention_mask=None, position_ids=None, packed=False,
-                       num_items_in_batch=None):
+                       num_items_in_batch=None, bf16_acts: bool = False):
     """One fwd + loss + autograd backward; grads keyed like `sd`. F.embedding(padding_idx=pad)
     suppresses the gather-side gradient of the pad row exactly like nn.Embedding(padding_idx)
     (hf: modeling_qwen2.py:327); the tied head still contributes to that row (SURVEY.md §7 iii)."""
@@ -262,7 +262,7 @@ def forward_loss_grads(cfg, sd, input_ids, labels, attention_mask=None, position
     E = params["lm.model.embed_tokens.weight"]
     pad = cfg.pad_token_id if (cfg.pad_token_id is not None and cfg.pad_token_id >= 0) else None
     h0 = F.embedding(input_ids, E, padding_idx=pad)
-    logits = decoder_stack(cfg, params, h0, E, attention_mask, position_ids, packed)
+    logits = decoder_stack(cfg, params, h0, E, attention_mask, position_ids, packed, bf16_acts)
     loss = compute_loss(logits, labels, num_items_in_batch)
     loss.backward()
     return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in params.items()}
