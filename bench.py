@@ -151,8 +151,10 @@ def hbm_kernel_rates(model, trainer):
 
     us = _time_us(lambda: lib.slam_op_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), M, H, 1e-6, st))
     row("rmsnorm_fwd_kernel [8192 x 896]", us, 4 * M * H, "4 B/elem: bf16 read + bf16 write")
+    # (dw = NULL: per-block weight-gradient partials only, as the engine launches it - the column sums of a whole
+    #  gradient bucket are finished in one batched launch)
     us = _time_us(lambda: lib.slam_op_rmsnorm_bwd(y.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), x.data_ptr(), dx.data_ptr(),
-                                                   dw.data_ptr(), ws.data_ptr(), M, H, st))
+                                                   None, ws.data_ptr(), M, H, st))
     row("rmsnorm_bwd_kernel [8192 x 896] (+ fused residual-gradient add)", us, 8 * M * H, "8 B/elem: x, dy, dres read + dx written")
     n = model.engine.n_params
     eng = model.engine

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU"; do
   i=$((i+1))
-  SLAM_BWD_WGRAD_STREAM=0 timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/${tag}_pmc_$i -o p -- \
+  timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/${tag}_pmc_$i -o p -- \
     python $R/tools/one_step.py "$@" > $R/gpurun_out/${tag}_pmc_$i.log 2>&1
   ls $R/gpurun_out/${tag}_pmc_$i/*/ 2>/dev/null | head -3
 done

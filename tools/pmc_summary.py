@@ -33,7 +33,7 @@ cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT
 with open(dst, "w") as f:
     f.write(f"# {title}\n\n")
     f.write("`tools/pmc_step.sh`: `rocprofv3 --kernel-trace --pmc <set>` over `tools/one_step.py` (three optimizer steps; one counter set per "
-            "pass, single-stream backward so that kernels do not overlap), dispatches of the last optimizer step, mean per launch. "
+            "pass; counter collection serialises the dispatches of the two backward streams), dispatches of the last optimizer step, mean per launch. "
             "`read MB` = FETCH_SIZE x 2 (gfx950 correction) x 1024 B; `written MB` = WRITE_SIZE x 1024 B. `mfma busy` = "
             "SQ_VALU_MFMA_BUSY_CYCLES / (GPU cycles x 4 SIMDs x 256 CUs), GPU cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); `wait` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked in "
             "s_waitcnt / barrier), `stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls); `lds conflict` = SQ_LDS_BANK_CONFLICT / "
