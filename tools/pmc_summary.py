@@ -37,7 +37,8 @@ with open(dst, "w") as f:
             "`read MB` = FETCH_SIZE x 2 (gfx950 correction) x 1024 B; `written MB` = WRITE_SIZE x 1024 B. `mfma busy` = "
             "SQ_VALU_MFMA_BUSY_CYCLES / (GPU cycles x 4 SIMDs x 256 CUs), GPU cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); `wait` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked in "
             "s_waitcnt / barrier), `stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls); `lds conflict` = SQ_LDS_BANK_CONFLICT / "
-            "SQ_LDS_IDX_ACTIVE.\n\n")
+            "SQ_LDS_IDX_ACTIVE. Launches with fewer than 256 one-per-CU blocks (the 256x224 kernels planned as background launches) show "
+            "their chip-level figure and, in brackets, the figure per OCCUPIED CU (x 256 / blocks).\n\n")
     f.write("| kernel | launches | read MB | written MB | GPU cycles | mfma busy | wait | stall | lds conflict |\n|---|---|---|---|---|---|---|---|---|\n")
     def mean(name, c):
         v = agg[name].get(c)
@@ -52,7 +53,12 @@ with open(dst, "w") as f:
         lc, li = mean(n, "SQ_LDS_BANK_CONFLICT"), mean(n, "SQ_LDS_IDX_ACTIVE")
         k = len(next(iter(agg[n].values())))
         fmt = lambda x, s="{:.1f}": "" if x is None else s.format(x)  # noqa: E731
+        busy = fmt(mb / (gr * 1024) if mb and gr else None, '{:.3f}')
+        import re
+        mblk = re.search(r"\[(\d+) blocks\]", n)
+        if busy and mblk and "_224_" in n and int(mblk.group(1)) < 256:
+            busy += f" ({mb / (gr * 1024) * 256 / int(mblk.group(1)):.2f})"
         f.write(f"| `{n[:70]}` | {k} | {fmt(fe * 2 * 1024 / 1e6 if fe is not None else None)} | {fmt(wr * 1024 / 1e6 if wr is not None else None)} | "
-                f"{fmt(gr, '{:.0f}')} | {fmt(mb / (gr * 1024) if mb and gr else None, '{:.3f}')} | {fmt(wa / wc if wa and wc else None, '{:.2f}')} | "
+                f"{fmt(gr, '{:.0f}')} | {busy} | {fmt(wa / wc if wa and wc else None, '{:.2f}')} | "
                 f"{fmt(wi / wc if wi and wc else None, '{:.2f}')} | {fmt(lc / li if lc is not None and li else None, '{:.3f}')} |\n")
 print(open(dst).read()[:3000])
