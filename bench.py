@@ -194,6 +194,24 @@ def extra_measurements(model, trainer, rank, dev, a):
         return {"tokens_per_s": round(world * B * T * ga * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
 
     res["grad_accum_16"] = run(trainer, 16, 3, 1)
+    # the boundary as the training loop crosses it: rows collated on the host (DataCollatorForLanguageModeling), CPU int64
+    # batches handed to UnitLM.forward (pageable H2D inside the step), token counts taken from the CPU labels
+    from slamkit_amd.data import DataCollatorForLanguageModeling
+    coll = DataCollatorForLanguageModeling(pad_token_id=0)
+    g = torch.Generator().manual_seed(77 + rank)
+    rows = [[{"input_ids": [1] + torch.randint(2, V, (T - 1,), generator=g).tolist(), "attention_mask": [1] * T} for _ in range(B)]
+            for _ in range(4)]
+    steps_h = max(5, min(a.steps, 20))
+    for i in range(3):
+        trainer.optimizer_step([coll(rows[i % 4])], 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps_h):
+        trainer.optimizer_step([coll(rows[i % 4])], 1e-3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res["host_boundary"] = {"tokens_per_s": round(world * B * T * steps_h / dt, 1), "ms_per_step": round(dt / steps_h * 1e3, 3), "steps": steps_h,
+                            "what": "collate on the host + CPU int64 batches through UnitLM.forward (H2D inside the step)"}
     args2 = SLAMTrainingArguments(per_device_train_batch_size=B, gradient_accumulation_steps=1, learning_rate=1e-3, max_grad_norm=0.5,
                                   logging_steps=0, optim_state_dtype="bfloat16",
                                   ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"))
