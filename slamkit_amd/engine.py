@@ -44,6 +44,10 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("SLAM_ENGINE_LIB", _LIB_PATH)
+    # PyTorch-ROCm first: its wheel carries its own libamdhip64; the engine library must bind to THAT runtime instance (the one
+    # that owns the device memory and streams it is handed), not to a second copy loaded from /opt/rocm before torch came up
+    # (kernel launches then fail with hipErrorNoDevice)
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise OSError(f"{p} not found: build it with `python -m slamkit_amd.csrc.build` "
                       f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")

@@ -230,7 +230,9 @@ def test_adamw_bf16_state_step_vs_oracle():
     assert int((got != p).sum()) <= n // 1000, int((got != p).sum())  # fp32 contraction (fma) differences: isolated 1-ulp cases (measured 0.03 %)
     assert float((got.float() - p.float()).abs().max()) <= 2 ** -7 * float(p.float().abs().max())
     for mine, ref in ((tr.exp_avg.cpu(), mo), (tr.exp_avg_sq.cpu(), vo)):
-        tol = 2.0 ** -7 * ref.float().abs() + 1e-6 * float(ref.float().abs().max())
+        # one bf16 ulp of the value, or - for elements where the lerp nearly cancels - a residue far below one ulp of the
+        # tensor's scale (the GPU contracts m + w (g - m) into one fma, the oracle rounds twice)
+        tol = 2.0 ** -7 * ref.float().abs() + 1e-4 * float(ref.float().abs().max())
         assert bool(((mine.float() - ref.float()).abs() <= tol).all())
     # the transposed weight images follow the in-place update
     k = "lm.model.layers.0.self_attn.o_proj.weight"
