@@ -231,9 +231,10 @@ def test_adamw_bf16_state_step_vs_oracle():
     assert float((got.float() - p.float()).abs().max()) <= 2 ** -7 * float(p.float().abs().max())
     for mine, ref in ((tr.exp_avg.cpu(), mo), (tr.exp_avg_sq.cpu(), vo)):
         # a one-ulp difference of a step (the GPU contracts m + w (g - m) into one fma, the oracle rounds twice) is carried
-        # into the next steps' bf16 state: up to 4 bf16 ulps after 5 steps (38 of 1.3 M elements beyond 2), or - where
-        # the lerp nearly cancels - a residue far below one ulp of the tensor's scale
-        tol = 2.0 ** -5 * ref.float().abs() + 1e-4 * float(ref.float().abs().max())
+        # into the next steps' bf16 state: up to 4 bf16 ulps after 5 steps (38 of 1.3 M elements beyond 2); where successive
+        # gradients cancel, the value is small but carries the ulps of the larger values it came from (measured: 1e-5
+        # absolute at a tensor scale of 9e-3): absolute floor of half an ulp at the tensor's scale
+        tol = 2.0 ** -5 * ref.float().abs() + 2e-3 * float(ref.float().abs().max())
         err = (mine.float() - ref.float()).abs()
         bad = err > tol
         assert not bool(bad.any()), (int(bad.sum()), mine[bad][:4].tolist(), ref[bad][:4].tolist(), float(ref.float().abs().max()))
