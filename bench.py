@@ -348,6 +348,59 @@ def bench_qwen1p5b(a, world, rank, dev):
         dist.destroy_process_group()
 
 
+def bench_dpo(a, world, rank, dev):
+    """Extra workload (not the BASELINE metric): BASELINE.json configs[4] / SURVEY.md §8d config 5 - the DPO step of
+    cli/preference_alignment_train.py on Slam-358M: 8 preference pairs per GPU (prompt ~U{25..75} units, chosen / rejected
+    ~U{50..150}), policy forward + backward over the 16 sequences, no-gradient reference forward, beta 0.1, clip + AdamW."""
+    from slamkit_amd.model import UnitLM, UnitLMConfig
+    from slamkit_amd.trainer import DPOConfig, SLAMDPOTrainer
+    cfg = dict(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=V, max_tokens=16 * 256)
+    model = UnitLM(UnitLMConfig(**cfg), seed=0)
+    ref = UnitLM(UnitLMConfig(**cfg), seed=0, allocate_grads=False)
+
+    class _Tok:  # rows below are already token ids
+        bos_token_id = eos_token_id = 1
+        def __call__(self, s, add_special_tokens=False):
+            return {"input_ids": list(s)}
+    g = torch.Generator().manual_seed(4321 + rank)
+    def ids(lo, hi):
+        return torch.randint(2, V, (int(torch.randint(lo, hi + 1, (1,), generator=g)),), generator=g).tolist()
+    pairs = [[{"prompt": ids(25, 75), "chosen": ids(50, 150), "rejected": ids(50, 150)} for _ in range(8)] for _ in range(4)]
+    args = DPOConfig(per_device_train_batch_size=8, learning_rate=5e-5, max_grad_norm=0.5, logging_steps=0, beta=0.1)
+    tr = SLAMDPOTrainer(model=model, ref_model=ref, args=args, train_dataset=[r for b in pairs for r in b], processing_class=_Tok())
+    batches = [tr._collate_pairs(tr.train_dataset[8 * i: 8 * i + 8]) for i in range(4)]
+    toks = [int((b["labels"] != -100).sum()) for b in batches]
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(a.warmup):
+        tr.optimizer_step([batches[i % 4]], 5e-5)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        tr.optimizer_step([batches[(a.warmup + i) % 4]], 5e-5)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        done = sum(toks[(a.warmup + i) % 4] for i in range(a.steps))
+        print(json.dumps({
+            "metric": "DPO preference pairs/sec (whole node), Slam-358M", "value": round(world * 8 * a.steps / dt, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[4]: DPO on Slam-358M, 8 pairs / GPU / step (16 sequences padded to a multiple of 64 tokens), policy "
+                                   "fwd+bwd + reference fwd, beta 0.1; full optimizer step", "parallelism": f"dp{world}",
+                       "completion_tokens_per_s": round(world * done / dt, 1), "tokens_per_batch": [int(b["input_ids"].numel()) for b in batches],
+                       "final_loss": round(float(tr._loss_acc) / max(1, tr._loss_n), 4)}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,8 +409,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the GA=16 and recipe-optimizer measurements after the timed region")
     ap.add_argument("--grad-accum", type=int, default=1)
-    ap.add_argument("--workload", default="slam358m", choices=["slam358m", "qwen1p5b"],
-                    help="slam358m = BASELINE.json configs[1] (the headline metric); qwen1p5b = configs[3]-shaped extra")
+    ap.add_argument("--workload", default="slam358m", choices=["slam358m", "qwen1p5b", "dpo"],
+                    help="slam358m = BASELINE.json configs[1] (the headline metric); qwen1p5b = configs[3]-shaped extra; dpo = configs[4] extra")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -391,6 +444,8 @@ def main():
 
     if a.workload == "qwen1p5b":
         return bench_qwen1p5b(a, world, rank, dev)
+    if a.workload == "dpo":
+        return bench_dpo(a, world, rank, dev)
 
     cfg = UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=V, max_tokens=B * T)
     model = UnitLM(cfg, seed=0)
