@@ -493,6 +493,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exposed = float(t)
 
+    # after the timed region, on EVERY rank (the steps inside contain the data-parallel collectives)
+    extras = None if a.no_extras else extra_measurements(model, trainer, rank, dev, a)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * trained_tokens * a.steps / dt
@@ -516,8 +518,8 @@ def main():
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
         out["roofline"] = roof
         out["hbm_kernels"] = hbm_kernel_rates(model, trainer)
-        if not a.no_extras:
-            out["extras"] = extra_measurements(model, trainer, rank, dev, a)
+        if extras is not None:
+            out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:
             del trainer, model
             torch.cuda.empty_cache()
