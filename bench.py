@@ -493,7 +493,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exposed = float(t)
 
-    # after the timed region, on EVERY rank (the steps inside contain the data-parallel collectives)
+    # after the timed region, on EVERY rank: the kernel probes touch the optimizer state (identically on all ranks), the
+    # extra steps contain the data-parallel collectives
+    hbm = hbm_kernel_rates(model, trainer)
     extras = None if a.no_extras else extra_measurements(model, trainer, rank, dev, a)
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -517,7 +519,7 @@ def main():
         roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
         out["roofline"] = roof
-        out["hbm_kernels"] = hbm_kernel_rates(model, trainer)
+        out["hbm_kernels"] = hbm
         if extras is not None:
             out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:
