@@ -28,6 +28,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: see slamkit_amd/__init__.py
+
 import torch
 import torch.distributed as dist
 

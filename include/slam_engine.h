@@ -100,6 +100,11 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
  * bucket_layers = decoder layers per gradient bucket for the callback (<=0: one bucket). */
 int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_bucket_cb cb, void* user,
                   slam_stream_t stream);
+/* Valid inside a slam_bucket_cb call: the stream on which the reported range is complete - the consumer records its
+ * "bucket ready" event THERE. NULL = the stream passed to slam_backward. With the weight-gradient stream on, the
+ * intermediate buckets are complete on that engine-owned stream (which has also been ordered after the norm / bias
+ * kernels of the range on `stream`), so `stream` itself never waits for the weight gradients at a bucket boundary. */
+slam_stream_t slam_bucket_stream(SlamEngine* h);
 
 /* Per-sequence log-likelihood sums of the last forward (UnitLM.log_likelihood :184-194 /
  * calc_nll, slamkit/utils/calculation_utils.py:5-29): ll_out, cnt_out fp32 [B] device. */

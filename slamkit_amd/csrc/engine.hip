@@ -80,6 +80,7 @@ struct SlamEngine {
   // kernel that produces its operands and every buffer re-use on the main stream after the wgrad that reads it.
   int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
   hipStream_t wside = nullptr;
+  hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
   ~SlamEngine() {
@@ -553,8 +554,12 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       fin_hi = l;
     }
     if (boundary) {
-      CK(wait_side(l, 6));  // the side stream is in order: its last launch of layer l covers every wgrad of the range
+      // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
+      // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
+      CK(fork(l, 7));
+      h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
+      h->bucket_stream = nullptr;
       bucket_end = o.ln1;
     }
   }
@@ -574,6 +579,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;
 }
+
+slam_stream_t slam_bucket_stream(SlamEngine* h) { return h ? (slam_stream_t)h->bucket_stream : nullptr; }
 
 int slam_set_logit_mask(SlamEngine* h, const uint8_t* mask) {
   if (!h) return SLAM_EINVAL;

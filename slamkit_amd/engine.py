@@ -68,6 +68,7 @@ def load_library(path: Optional[str] = None):
         "slam_bind_workspace": (C.c_int, [vp, vp, sz, i64]),
         "slam_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
         "slam_backward": (C.c_int, [vp, f32, i32, BUCKET_CB, vp, vp]),
+        "slam_bucket_stream": (vp, [vp]),
         "slam_set_logit_mask": (C.c_int, [vp, vp]),
         "slam_padded_vocab": (i32, [vp]),
         "slam_seq_loglik": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
@@ -205,7 +206,8 @@ class Engine:
         if bucket_cb is None:
             cb = C.cast(None, BUCKET_CB)
         else:
-            cb = BUCKET_CB(lambda _u, off, cnt: bucket_cb(int(off), int(cnt)))
+            # third argument: the stream the range is complete on (slam_bucket_stream; None = the backward stream)
+            cb = BUCKET_CB(lambda _u, off, cnt: bucket_cb(int(off), int(cnt), self.lib.slam_bucket_stream(self.h)))
         self._ck(self.lib.slam_backward(self.h, float(grad_scale), int(bucket_layers), cb, None,
                                         stream if stream is not None else current_stream_ptr()))
 

@@ -73,9 +73,10 @@ class GradBucketReducer:
         ev[1].synchronize()
         return float(ev[0].elapsed_time(ev[1]))
 
-    def on_bucket(self, offset: int, count: int):
+    def on_bucket(self, offset: int, count: int, ready_stream: Optional[int] = None):
         """Called by the engine (host side) right after the kernels producing grads[offset:offset+count]
-        were enqueued on the current stream."""
+        were enqueued. ready_stream: raw handle of the stream the range is complete on (slam_bucket_stream: the engine's
+        weight-gradient stream for the intermediate buckets); None = the current stream."""
         self.ranges.append((offset, count))
         if (self.world == 1 and not self.force) or count <= 0:
             return
@@ -84,7 +85,8 @@ class GradBucketReducer:
             self.stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
         if self.side is not None:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.flat.device))
+            ev.record(torch.cuda.ExternalStream(ready_stream, device=self.flat.device) if ready_stream
+                      else torch.cuda.current_stream(self.flat.device))
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
                 if self.comm_dtype is None:

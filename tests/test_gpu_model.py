@@ -154,7 +154,7 @@ def test_backward_bucket_ranges_tile_the_flat_gradient(tiny, golden_npz):
     got = []
     m.zero_grad()
     m(input_ids=ids, labels=lab, return_logits=False)
-    m.backward(1.0, 1, lambda off, cnt: got.append((off, cnt)))
+    m.backward(1.0, 1, lambda off, cnt, stream=None: got.append((off, cnt)))
     torch.cuda.synchronize()
     n = m.engine.n_params
     assert got[0][0] + got[0][1] == n and got[-1][0] == 0
@@ -163,6 +163,35 @@ def test_backward_bucket_ranges_tile_the_flat_gradient(tiny, golden_npz):
     t = m.engine.tensors
     assert got[-1][1] == t["layers.1.ln1"].offset  # embedding + layer 0
 
+
+
+def test_bucket_ranges_are_final_on_the_reported_stream(tiny, golden_npz):
+    """slam_bucket_stream: a consumer that orders itself ONLY after the stream reported with a bucket (the engine's
+    weight-gradient stream for the intermediate buckets, the backward stream for the last) reads the final gradient of
+    that range - the contract the data-parallel reducer relies on, with main never waiting at a boundary."""
+    cfg, sd, sd_bf, m = tiny
+    ids, lab = (torch.from_numpy(golden_npz[k]) for k in ("pad_ids", "pad_labels"))
+    consumer = torch.cuda.Stream()
+    for two in (1, 0):
+        m.engine.set_option("bwd_wgrad_stream", two)
+        snaps, streams = [], []
+
+        def cb(off, cnt, stream=None):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream())
+            consumer.wait_event(ev)
+            with torch.cuda.stream(consumer):
+                snaps.append((off, cnt, m.flat_grads[off:off + cnt].clone()))
+            streams.append(stream)
+        for rep in range(2):
+            m.zero_grad()
+            m(input_ids=ids, labels=lab, return_logits=False)
+            m.backward(1.0, 1, cb)
+        torch.cuda.synchronize()
+        assert streams[-1] is None and (all(s for s in streams[:len(streams) // 2 - 1]) if two else not any(streams))
+        for off, cnt, snap in snaps[len(snaps) // 2:]:
+            assert torch.equal(snap, m.flat_grads[off:off + cnt]), (two, off, cnt)
+    m.engine.set_option("bwd_wgrad_stream", 1)
 
 
 def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
@@ -179,7 +208,7 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
         got = []
         for rep in range(3):  # back-to-back backwards: the side stream of one must not run into the next
             m(input_ids=ids, labels=lab, return_logits=False)
-            m.backward(0.5 if rep else 1.0, 1, lambda off, cnt: got.append((off, cnt)))
+            m.backward(0.5 if rep else 1.0, 1, lambda off, cnt, stream=None: got.append((off, cnt)))
         torch.cuda.synchronize()
         return m.flat_grads.clone(), got
 
