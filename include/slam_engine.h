@@ -149,7 +149,7 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
  * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
- * "gemm_256_dswiglu", "gemm_tn224", "gemm_tn_balanced", "gemm_group_rows" select kernels. */
+ * "gemm_256_dswiglu", "gemm_256_persist", "gemm_tn224", "gemm_tn_balanced", "gemm_group_rows" select kernels. */
 int slam_set_option(SlamEngine* h, const char* key, int64_t value);
 
 /* ---- single-op entry points (parity tests call each kernel through the ABI) -------------------*/
@@ -158,6 +158,9 @@ int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, con
 /* gate|up projection with the SwiGLU product fused into the epilogue (W rows in 32-row gate/up blocks):
  * Y[M,N] = X W^T and act[M,N/2] = silu(gate) * up. The dominant kernel of the step (bench.py roofline). */
 int slam_op_gemm_nt_swiglu(const void* X, const void* W, void* Y, void* act, int M, int N, int K, slam_stream_t s);
+/* down-projection dgrad with the SwiGLU backward fused into the epilogue: d(act)[M,I] = dY[M,H] Wt[I,H]^T never leaves the
+ * registers; gu[M,2I] (gate|up pre-activations, 32-column gate/up blocks) is rewritten in place with d(gate|up). */
+int slam_op_gemm_nt_dswiglu(const void* dY, const void* Wt, void* gu, int M, int I, int H, slam_stream_t s);
 int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s);
 size_t slam_op_gemm_tn_workspace(int M, int N, int K);
 int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,

@@ -361,6 +361,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_group_rows")) { gemm_set_group_rows((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
+  if (!strcmp(key, "gemm_256_persist")) { gemm_set_256_persist((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt224")) { gemm_set_nt224((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_nt224_min_k")) { gemm_set_nt224_min_k((int)value); return SLAM_OK; }
@@ -694,6 +695,9 @@ int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, con
 }
 int slam_op_gemm_nt_swiglu(const void* X, const void* W, void* Y, void* act, int M, int N, int K, slam_stream_t s) {
   return gemm_nt_swiglu((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (bf16_t*)act, M, N, K, (hipStream_t)s);
+}
+int slam_op_gemm_nt_dswiglu(const void* dY, const void* Wt, void* gu, int M, int I, int H, slam_stream_t s) {
+  return gemm_nt_dswiglu((const bf16_t*)dY, (const bf16_t*)Wt, (bf16_t*)gu, M, I, H, (hipStream_t)s);
 }
 int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, int M, int N, int K, slam_stream_t s) {
   return gemm_nn((const bf16_t*)dY, (const bf16_t*)W, (bf16_t*)dX, (const bf16_t*)resid, M, N, K, (hipStream_t)s);

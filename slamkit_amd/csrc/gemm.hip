@@ -201,7 +201,19 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 
 // Epilogue of the 8-column layout: lane (l15, g) of wave (wm, wn) holds C[m][cw + 32q .. +7] for
 // q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout. Fused: bias, residual, RoPE, SwiGLU fwd / bwd.
-SLAM_DEVICE void epilogue8(const GemmArgs& p, const f32x4_t (&acc)[4][4], int row0, int col0, int wm, int wn, int l15, int g) {
+// LEAN: plain / SwiGLU forward / SwiGLU backward only (no bias, residual or RoPE operands compiled in) - the persistent
+// 256 x 256 kernel must not carry a conditionally consumed load around its tile loop: the compiler would wait for it
+// (vmcnt) inside the next tile's first K-tile, and that wait also covers the epilogue's stores.
+template <bool LEAN = false>
+SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int row0, int col0, int wm, int wn, int l15, int g) {
+  struct Lean {  // the fields the fused paths read, with the optional operands pinned to null
+    const GemmArgs& a;
+    void* C; bf16_t* act; bf16_t* gu; int R, Cn, ldc, nt_store;
+    const bf16_t* bias; const bf16_t* resid; const float* rope_cos; const float* rope_sin; int rope_heads;
+  };
+  const Lean p = {p_, p_.C, p_.act, p_.gu, p_.R, p_.Cn, p_.ldc, p_.nt_store,
+                  LEAN ? nullptr : p_.bias, LEAN ? nullptr : p_.resid, LEAN ? nullptr : p_.rope_cos,
+                  LEAN ? nullptr : p_.rope_sin, LEAN ? 0 : p_.rope_heads};
   // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
   const int cw = col0 + wn * 64 + g * 8;  // + 32 q
   uint4 bb4[2];
@@ -639,6 +651,14 @@ SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // (measured against this schedule: one barrier per phase without the wave-row stagger +3 % time, no priority raise +8 %;
 //  round 2: starting groups of first-round blocks a fraction of a tile period late, to de-synchronise the epilogue store
 //  bursts of the 256 resident blocks, moves the fused gate|up launch by <= 4 % in isolation and the step by nothing)
+// PERSIST: gridDim.x (a multiple of 8, <= the CU count) blocks walk the tile list instead of one block per tile - XCD x
+// keeps its contiguous range of tile ids, slot s of the XCD takes ids s, s + slots, ... (the co-running set of a round is
+// the one the dispatcher produces for the one-tile-per-block grid). The DMA stream does not stop at a tile boundary: the
+// last K-tile of a tile issues the first K-tile of the next one (steady-state waits), the block then drains ITS loads
+// (vmcnt counts stores and loads in one in-order queue: a counted wait after the epilogue would wait for the stores),
+// stores the finished tile and continues with a K-tile whose first two phases need no wait. Dispatch, address set-up and
+// the first-load latency of a tile disappear behind the previous tile's epilogue.
+template <bool PERSIST>
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
@@ -647,41 +667,59 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
   const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
+  int nid, nid_end, nid_step;
   {
     int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
     int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    nid = base + idx;
+    nid_end = PERSIST ? base + q + (xcd < r ? 1 : 0) : nid + 1;
+    nid_step = PERSIST ? (int)(gridDim.x >> 3) : 1;
   }
-  int tr_, tc_;
-  {
+  auto tile_origin = [&](int id, int& r0, int& c0) {
     const int GR = p.group_rows > 0 ? p.group_rows : 1;
     const int per_group = GR * p.tiles_c;
-    const int grp = nid / per_group, in = nid - grp * per_group;
+    const int grp = id / per_group, in = id - grp * per_group;
     const int rows_here = min(GR, p.tiles_r - grp * GR);
-    tc_ = in / rows_here;
-    tr_ = grp * GR + in - tc_ * rows_here;
-  }
-  const int row0 = tr_ * 256, col0 = tc_ * 256;
+    const int tc_ = in / rows_here;
+    r0 = (grp * GR + in - tc_ * rows_here) * 256;
+    c0 = tc_ * 256;
+  };
+  int row0, col0;
+  tile_origin(nid, row0, col0);
   const int nk = p.Kc / BK;
   const uint32_t lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   // DMA source offsets, 2 chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
   uint32_t vo[4][2];
+  // fragment addresses inside a half-tile: byte offsets of row (wave block + f*16 + l15), without the chunk term
+  int ka, offA[4], offB[2];
+  // per-lane constants of the K loop. A persistent block computes them again after every epilogue (from an opaque copy
+  // of the thread id, so that the compiler cannot keep the first set alive): they stay out of the epilogue's live range
+  auto lane_setup = [&](int t_) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int P = i * 512 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
+    for (int i = 0; i < 2; ++i) {
+      const int P = i * 512 + t_, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int grow = (r >> 6) * 128 + h * 64 + (r & 63);          // relative to the tile origin: 32-bit offsets must not
-      const int gcol = (r >> 5) * 64 + perm64(h * 32 + (r & 31));   // span the matrix (dlogits [16384][152320] is 4.99 GB)
-      vo[h ? 3 : 0][i] = (uint32_t)(((size_t)grow * p.lda + c * 8) * sizeof(bf16_t));
-      vo[1 + h][i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
+      for (int h = 0; h < 2; ++h) {
+        const int grow = (r >> 6) * 128 + h * 64 + (r & 63);          // relative to the tile origin: 32-bit offsets must not
+        const int gcol = (r >> 5) * 64 + perm64(h * 32 + (r & 31));   // span the matrix (dlogits [16384][152320] is 4.99 GB)
+        vo[h ? 3 : 0][i] = (uint32_t)(((size_t)grow * p.lda + c * 8) * sizeof(bf16_t));
+        vo[1 + h][i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
+      }
     }
-  }
-  auto issue_half = [&](int h, int t) {  // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1)
-    const bf16_t* base = ((h == 0 || h == 3) ? p.A + (size_t)row0 * p.lda : p.B + (size_t)col0 * p.ldb) + (size_t)t * BK;
-    const uint32_t dst = lds0 + (uint32_t)((t & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
+    const int l15_ = t_ & 15;
+    ka = (l15_ >> 1) & 7;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) offA[f] = (wr * 64 + f * 16 + l15_) * 128;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) offB[f] = (wc * 32 + f * 16 + l15_) * 128;
+  };
+  lane_setup(tid);
+  // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1); ta / tb: the K-tile's origin in A / B; par: buffer
+  auto issue_half = [&](int h, const bf16_t* ta, const bf16_t* tb, int par) {
+    const bf16_t* base = (h == 0 || h == 3) ? ta : tb;
+    const uint32_t dst = lds0 + (uint32_t)(par * KT + h * HT) + (uint32_t)wv * 1024u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
   };
@@ -694,13 +732,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // fragment addresses inside a half-tile
-  const int ka = (l15 >> 1) & 7;
-  int offA[4], offB[2];  // byte offsets of row (wave block + f*16 + l15), without the chunk term
-#pragma unroll
-  for (int f = 0; f < 4; ++f) offA[f] = (wr * 64 + f * 16 + l15) * 128;
-#pragma unroll
-  for (int f = 0; f < 2; ++f) offB[f] = (wc * 32 + f * 16 + l15) * 128;
   uint4 afr[2][4], bfr[2][2][2];  // [kk][fm], [nq][kk][fn]
   auto read_A = [&](const char* half) {
 #pragma unroll
@@ -728,52 +759,103 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
           acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
     __builtin_amdgcn_s_setprio(0);
   };
-  auto ktile = [&](int t, auto last_tag) {
-    constexpr bool LAST = decltype(last_tag)::value;
-    const char* buf = smem + (t & 1) * KT;
+  // MODE 0: steady state (issues the K-tile at na / nb into the other buffer); 1: last K-tile of the block (nothing to
+  // issue, waits drain); 2: first K-tile after a tile boundary of a persistent block - its own half-tiles were drained
+  // before the epilogue, and a counted wait in phases 1 / 2 would wait for the epilogue's stores
+  auto ktile = [&](int par, auto mode_tag, const bf16_t* na, const bf16_t* nb) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool LAST = MODE == 1;
+    const char* buf = smem + par * KT;
     // phase 1
-    if (!LAST) issue_half(0, t + 1);
+    if (!LAST) issue_half(0, na, nb, par ^ 1);
     read_A(buf);
     read_B(buf + HT, 0);
-    wait_ph<LAST>(0);  // Bnq1(t) landed -> read in phase 2
+    if (MODE != 2) wait_ph<LAST>(0);  // Bnq1(t) landed -> read in phase 2
     raw_barrier();
     mma(0, 0);
     barrier_b();
     // phase 2
-    if (!LAST) issue_half(1, t + 1);
+    if (!LAST) issue_half(1, na, nb, par ^ 1);
     read_B(buf + 2 * HT, 1);
-    wait_ph<LAST>(1);  // Amq1(t) landed -> read in phase 3
+    if (MODE != 2) wait_ph<LAST>(1);  // Amq1(t) landed -> read in phase 3
     raw_barrier();
     mma(0, 1);
     barrier_b();
     // phase 3
-    if (!LAST) issue_half(2, t + 1);
+    if (!LAST) issue_half(2, na, nb, par ^ 1);
     read_A(buf + 3 * HT);
     raw_barrier();
     mma(1, 1);
     barrier_b();
     // phase 4
-    if (!LAST) issue_half(3, t + 1);
+    if (!LAST) issue_half(3, na, nb, par ^ 1);
     wait_ph<LAST>(2);  // Amq0(t+1), Bnq0(t+1) landed -> read in phase 1 of the next K-tile
     raw_barrier();
     mma(1, 0);
     barrier_b();
   };
+  using steady_t = std::integral_constant<int, 0>;
+  using last_t = std::integral_constant<int, 1>;
+  using first_t = std::integral_constant<int, 2>;
 
   // prologue: K-tile 0 in the order it is needed; phase 1 needs the first two half-tiles
-  issue_half(0, 0);
-  issue_half(1, 0);
-  issue_half(2, 0);
-  issue_half(3, 0);
-  wait_vmcnt<4>();
-  raw_barrier();
-  if (wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
-  for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
-  ktile(nk - 1, std::true_type{});
-  if (wr == 0) raw_barrier();  // balance the barrier count
-
-  epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
-  epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
+  const bf16_t* ta = p.A + (size_t)row0 * p.lda;
+  const bf16_t* tb = p.B + (size_t)col0 * p.ldb;
+  issue_half(0, ta, tb, 0);
+  issue_half(1, ta, tb, 0);
+  issue_half(2, ta, tb, 0);
+  issue_half(3, ta, tb, 0);
+  if constexpr (!PERSIST) {
+    wait_vmcnt<4>();
+    raw_barrier();
+    if (wr == 1) raw_barrier();  // second wave row: one barrier behind from here on
+    for (int t = 0; t + 1 < nk; ++t) ktile(t & 1, steady_t{}, ta + (size_t)(t + 1) * BK, tb + (size_t)(t + 1) * BK);
+    ktile((nk - 1) & 1, last_t{}, nullptr, nullptr);
+    if (wr == 0) raw_barrier();  // balance the barrier count
+    epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
+    epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
+  } else {
+    // one loop body for every tile (no variant diamonds: the accumulators keep their registers): the first K-tile of a
+    // tile finds its half-tiles drained, the last one issues the next tile's first K-tile - or, on the block's last tile,
+    // this tile's first K-tile once more (64 KB of L2 reads per block, never consumed)
+    wait_vmcnt<0>();
+    raw_barrier();
+    int par = 0;
+    for (;;) {
+      const int nnext = nid + nid_step;
+      const bool has_next = nnext < nid_end;
+      if (wr == 1) raw_barrier();  // second wave row: one barrier behind inside a tile
+      ktile(par, first_t{}, ta + BK, tb + BK);
+      par ^= 1;
+      for (int t = 1; t + 1 < nk; ++t) {
+        ktile(par, steady_t{}, ta + (size_t)(t + 1) * BK, tb + (size_t)(t + 1) * BK);
+        par ^= 1;
+      }
+      int nrow0 = row0, ncol0 = col0;
+      if (has_next) tile_origin(nnext, nrow0, ncol0);
+      ta = p.A + (size_t)nrow0 * p.lda;
+      tb = p.B + (size_t)ncol0 * p.ldb;
+      ktile(par, steady_t{}, ta, tb);  // the DMA stream runs on into the next tile
+      par ^= 1;
+      if (wr == 0) raw_barrier();  // balance the barrier count: both wave rows leave the tile together
+      wait_vmcnt<0>();             // this wave's pieces of the next tile's first K-tile (see MODE 2)
+      int l15e = l15, ge = g;
+      asm volatile("" : "+v"(l15e), "+v"(ge));  // keeps the epilogue's address arithmetic out of the K loop
+      epilogue8<true>(p, acc[0], row0 + wr * 128, col0, 0, wc, l15e, ge);
+      epilogue8<true>(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15e, ge);
+      if (!has_next) break;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      nid = nnext; row0 = nrow0; col0 = ncol0;
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      lane_setup(t_);
+    }
+  }
 }
 
 // ---- wgrad with balanced K-splitting ----------------------------------------------------------------
@@ -1409,18 +1491,29 @@ static int g_gemm_256_dswiglu = 1;
 void gemm_set_256_dswiglu(int on) { g_gemm_256_dswiglu = on; }
 static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
 void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
+// persistent blocks (one per CU) walking the tile list with the DMA stream running across tile boundaries: 0 = one
+// block per tile, 1 = whenever there are more tiles than CUs and the epilogue has no bias / residual / RoPE operand.
+// Same box, interleaved: gate|up forward + SwiGLU 147.4 -> 136.3 us, plain 130.0 -> 121.5, down-proj dgrad + dSwiGLU
+// 109.1 -> 104.7, LM head of the 152k vocabulary 6294 -> 6106; Slam-358M step 313.4 k -> 319.7 k tok/s (two pairs)
+static int g_gemm_256_persist = 1;
+void gemm_set_256_persist(int on) { g_gemm_256_persist = on; }
 static int launch_256(GemmArgs a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+  static int cus = 0;
+  if (!cus) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    cus = n & ~7;
   }
   a.tiles_r = a.R / 256;
   a.tiles_c = a.Cn / 256;
   a.group_rows = g_group_rows_256;
   a.nt_store = g_nt_store;
-  gemm_nt_256_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
+  const int tiles = a.tiles_r * a.tiles_c;
+  if (g_gemm_256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
+  else gemm_nt_256_kernel<false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
 

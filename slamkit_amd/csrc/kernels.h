@@ -14,6 +14,7 @@ void gemm_set_tn_dma(int on);
 void gemm_set_tn_splits(int s);
 void gemm_set_group_rows(int g);
 void gemm_set_nt_store(int on);
+void gemm_set_256_persist(int on);
 void gemm_set_256(int on);
 void gemm_set_shared(int on);
 void gemm_set_nt224(int v);

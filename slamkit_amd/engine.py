@@ -82,6 +82,7 @@ def load_library(path: Optional[str] = None):
         "slam_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "slam_op_gemm_nt": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "slam_op_gemm_nt_swiglu": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "slam_op_gemm_nt_dswiglu": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "slam_op_gemm_nn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "slam_op_gemm_tn_workspace": (sz, [C.c_int, C.c_int, C.c_int]),
         "slam_op_gemm_tn": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

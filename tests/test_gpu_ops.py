@@ -59,6 +59,42 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 8192, 192), (4352, 4096, 64 * 5), (8192, 9728, 896), (4096, 4864, 128)])
+def test_gemm_nt_256_persistent_blocks(M, N, K):
+    """gemm_256_persist: one block per CU walking the tile list, the DMA stream running across tile boundaries - same bits
+    as one block per tile (same contraction order per tile) for the plain, fused-SwiGLU-forward and fused-SwiGLU-backward
+    epilogues, on grids with ragged last rounds (288, 272, 1216, 304 tiles); the SwiGLU backward against fp32 as well."""
+    X, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    GU = rnd(M, 2 * N, seed=5)
+    Xd, Wd, gud = dev_bf16(X), dev_bf16(W), dev_bf16(GU)
+    outs = {}
+    try:
+        assert lib().slam_set_option(None, b"gemm_256", 2) == 0
+        for persist in (0, 1, 1):
+            assert lib().slam_set_option(None, b"gemm_256_persist", persist) == 0
+            Yp = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Yp), None, None, M, N, K, 2, stream()) == 0
+            Ys = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            act = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert lib().slam_op_gemm_nt_swiglu(ptr(Xd), ptr(Wd), ptr(Ys), ptr(act), M, N, K, stream()) == 0
+            g = gud.clone()
+            assert lib().slam_op_gemm_nt_dswiglu(ptr(Xd), ptr(Wd), ptr(g), M, N, K, stream()) == 0
+            sync()
+            outs.setdefault(persist, []).append((Yp, Ys, act, g))
+    finally:
+        lib().slam_set_option(None, b"gemm_256_persist", 1)
+        lib().slam_set_option(None, b"gemm_256", 1)
+    for run in outs[1]:
+        for a, b in zip(outs[0][0], run):
+            assert torch.equal(a, b)
+    d = (dev_bf16(X).float() @ dev_bf16(W).float().t()).cpu()  # d(act) [M][N]
+    gu = dev_bf16(GU).float().cpu().view(M, N // 32, 2, 32)
+    gate, up = gu[:, :, 0].reshape(M, N), gu[:, :, 1].reshape(M, N)
+    sg = torch.sigmoid(gate)
+    ref = torch.stack([(d * up * sg * (1 + gate * (1 - sg))).view(M, N // 32, 32), (d * gate * sg).view(M, N // 32, 32)], 2)
+    check("gemm 256 persistent dswiglu", outs[1][0][3].float().cpu().view(M, N // 32, 2, 32), ref, 6e-3, 3e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 224, 128), (512, 896, 64 * 5), (1024, 448, 64 * 19), (8192, 896, 1152)])
 def test_gemm_nt_224_tile_kernel(M, N, K):
     """The 256 x 224 / 8-wave / 8-phase NT kernel (dgrad launches of the two-stream backward), forced on: same bits as the

@@ -1,6 +1,7 @@
 """Race screen for the phase-scheduled kernels: many launches on fresh random data (a DMA read before its wait shows up as
 rare wrong tiles, not as a steady error).
-  gemm_nt_256_kernel, gemm_nt_224_kernel : every output bit for bit against the 128 x 128 kernel (same contraction order);
+  gemm_nt_256_kernel (one block per tile and persistent blocks), gemm_nt_224_kernel : every output bit for bit against the
+  128 x 128 kernel (same contraction order);
   gemm_tn_224_kernel (both orientations, with and without K-splitting): against the balanced 128 x 128 wgrad kernel to fp32
   summation-order tolerance per element, and bit for bit against a second launch of itself.
 Usage: python tools/gemm_256_race_screen.py [launches]"""
@@ -19,18 +20,20 @@ for it in range(iters):
     x = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     outs = []
-    for mode in (0, 2):
+    for mode, persist in ((0, 0), (2, 0), (2, 1)):
         lib.slam_set_option(None, b"gemm_256", mode if opt == "gemm_256" else 0)
+        lib.slam_set_option(None, b"gemm_256_persist", persist)
         lib.slam_set_option(None, b"gemm_nt224", mode if opt == "gemm_nt224" else 0)
         y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         assert lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 2, st) == 0
         outs.append(y)
     torch.cuda.synchronize()
-    if not torch.equal(outs[0], outs[1]):
-        bad += 1
-        d = (outs[0].float() - outs[1].float()).abs()
-        print(f"MISMATCH nt it={it} {opt} shape={M}x{N}x{K} max={float(d.max())} count={int((d > 0).sum())}", flush=True)
-lib.slam_set_option(None, b"gemm_256", 1); lib.slam_set_option(None, b"gemm_nt224", 1)
+    for k, o in enumerate(outs[1:]):
+        if not torch.equal(outs[0], o):
+            bad += 1
+            d = (outs[0].float() - o.float()).abs()
+            print(f"MISMATCH nt it={it} {opt} persist={k} shape={M}x{N}x{K} max={float(d.max())} count={int((d > 0).sum())}", flush=True)
+lib.slam_set_option(None, b"gemm_256", 1); lib.slam_set_option(None, b"gemm_nt224", 1); lib.slam_set_option(None, b"gemm_256_persist", 1)
 tn_shapes = [(8192, 9728, 896), (8192, 896, 4864), (4096, 512, 448), (16384, 1536, 8960), (2048, 1792, 1024)]
 for it in range(iters):
     M, N, K = tn_shapes[it % len(tn_shapes)]
