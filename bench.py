@@ -104,14 +104,15 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_256_kernel (NT, 256x256x64 tiles, 8 waves, 8-phase LDS-DMA schedule) gate|up + fused SwiGLU, M8192 N9728 K896",
+    return {"bound": "mfma", "kernel": "gemm_nt_256_kernel (NT, 256x256x64 tiles, 8 waves, 8-phase LDS-DMA schedule, persistent blocks) gate|up + fused SwiGLU, M8192 N9728 K896",
             "achieved": round(ach, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
             # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
-            # same kernel and shape: a RECORDED measurement (profiles/r2_pmc_step.md: 213.2 MB read + 239.1 MB written, the
-            # kernel is unchanged since round 1), not collected live - counters need rocprofv3 around the process
-            "traffic": 452.3e6, "traffic_source": "recorded: profiles/r2_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+            # same shape with one block per tile: a RECORDED measurement (profiles/r2_pmc_step.md: 213.2 MB read + 239.1 MB
+            # written), not collected live - counters need rocprofv3 around the process. The persistent launch walks the same
+            # tiles in the same co-running sets (+ 16 MB of never-consumed prefetch at the blocks' ends).
+            "traffic": 452.3e6, "traffic_source": "recorded: profiles/r2_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; one-block-per-tile launch of the same kernel)",
             "algorithmic_bytes": 271.2e6}
 
 
