@@ -206,12 +206,11 @@ SLAM_DEVICE void glds_offsets_tr(int ld, int row0, int tid, uint32_t* voff) {
 // (vmcnt) inside the next tile's first K-tile, and that wait also covers the epilogue's stores.
 template <bool LEAN = false>
 SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int row0, int col0, int wm, int wn, int l15, int g) {
-  struct Lean {  // the fields the fused paths read, with the optional operands pinned to null
-    const GemmArgs& a;
+  struct Fields {  // what the fused paths read; LEAN pins the optional operands to null at compile time
     void* C; bf16_t* act; bf16_t* gu; int R, Cn, ldc, nt_store;
     const bf16_t* bias; const bf16_t* resid; const float* rope_cos; const float* rope_sin; int rope_heads;
   };
-  const Lean p = {p_, p_.C, p_.act, p_.gu, p_.R, p_.Cn, p_.ldc, p_.nt_store,
+  const Fields p = {p_.C, p_.act, p_.gu, p_.R, p_.Cn, p_.ldc, p_.nt_store,
                   LEAN ? nullptr : p_.bias, LEAN ? nullptr : p_.resid, LEAN ? nullptr : p_.rope_cos,
                   LEAN ? nullptr : p_.rope_sin, LEAN ? 0 : p_.rope_heads};
   // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
