@@ -78,6 +78,7 @@ struct SlamEngine {
   // chain leaves idle: the N = 896 launches occupy 448 of 512 block slots, and a kernel in its HBM-bound epilogue
   // (down-proj dgrad with the fused SwiGLU backward) leaves the MFMA pipes free. Event pairs order every wgrad after the
   // kernel that produces its operands and every buffer re-use on the main stream after the wgrad that reads it.
+  AttnTune attn_tune = attn_default_tune();
   int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
   hipStream_t wside = nullptr;
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
@@ -172,7 +173,7 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->dqkv = c.take<bf16_t>(M * e->QKV);
   e->d_o = c.take<bf16_t>(M * d.n_heads * d.head_dim);
   e->dsum = c.take<float>(M * d.n_heads);
-  e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_heads, d.head_dim) / sizeof(float));
+  e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_kv_heads, d.head_dim) / sizeof(float));
   e->cosb = c.take<float>(M * (d.head_dim / 2));
   e->sinb = c.take<float>(M * (d.head_dim / 2));
   e->seg_s = c.take<int>(M);
@@ -374,6 +375,14 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_tn_bal_bg_max_split")) { gemm_set_tn_bal_bg_max_split((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224_bg_min_m")) { gemm_set_tn224_bg_min_m((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224_bg_max_split")) { gemm_set_tn224_bg_max_split((int)value); return SLAM_OK; }
+  if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch")) {
+    // with an engine: that engine's launches (takes effect at its next forward, which rebuilds the attention plan);
+    // without: the process default picked up by the single-op entry points and by engines created afterwards
+    AttnTune t = h ? h->attn_tune : attn_default_tune();
+    (key[5] == 'j' ? t.jq : key[5] == 'k' ? t.kw : t.nch) = (int)value;
+    if (h) { h->attn_tune = t; h->have_fwd = false; } else attn_set_default_tune(t);
+    return SLAM_OK;
+  }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
@@ -406,7 +415,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     h->cur_seg_s = h->seg_s;
     h->cur_seg_e = h->seg_e;
   }
-  CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, h->attn_plan_buf, st));
+  CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, d.head_dim, h->attn_tune, h->attn_plan_buf, st));
   CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
   CK(wait_chunk(h, 0, st));
   CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
@@ -533,8 +542,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     CK(mark(l, 5));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->cosb, h->sinb, M,
-                nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
+                M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
     CK(fork(l, 3));
     CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, ws, two ? 1 : 0));
@@ -734,18 +743,20 @@ int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_s
   return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
 }
 size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim) {
+  // the ABI call has no KV-head count: sized for nKV = nH (plain multi-head attention), the largest case
   return attn_bwd_workspace_bytes(M, nH, head_dim) + (size_t)M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
 }
 int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
                      const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, int head_dim,
                      slam_stream_t s) {
-  float* dsum = ws;
+  float* ndsum = ws;
   float* part = ws + (size_t)M * nH;
   int* plan = reinterpret_cast<int*>(part + attn_bwd_workspace_bytes(M, nH, head_dim) / sizeof(float));
-  int r = attn_plan(seg_start, seg_end, M, plan, (hipStream_t)s);
+  const AttnTune tune = attn_default_tune();
+  int r = attn_plan(seg_start, seg_end, M, head_dim, tune, plan, (hipStream_t)s);
   if (r) return r;
-  return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, dsum, (bf16_t*)dqkv, part, seg_start,
-                  seg_end, plan, nullptr, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
+  return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, ndsum, (bf16_t*)dqkv, part, seg_start,
+                  seg_end, plan, tune, nullptr, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
 }
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,
                           float* scratch2, int B, int T, int Vp, int V, slam_stream_t s) {

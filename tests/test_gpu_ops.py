@@ -355,6 +355,49 @@ def test_attention_fwd_bwd(seg_lens, nH, nKV, spike, hd):
     check("attn bwd dv", got[:, (nH + nKV) * hd:], dqkv_ref[:, (nH + nKV) * hd:], 1.5e-2, 6e-2)
 
 
+_ATTN_REF_CACHE = {}
+
+
+@pytest.mark.parametrize("jq,kw,nch", [(2, 1, 4), (1, 2, 4), (2, 2, 1), (1, 1, 1), (1, 1, 2), (2, 2, 3)])
+@pytest.mark.parametrize("seg_lens,nH,nKV", [([256, 256], 14, 2), ([37, 100, 5, 130, 64], 4, 2), ([1024], 7, 1),
+                                             ([29, 41, 17], 4, 2), ([700, 324], 6, 3)])
+def test_attention_bwd_launch_shapes(seg_lens, nH, nKV, jq, kw, nch):
+    """Every launch shape of the backward (rows per wave in dQ, keys per wave in dK/dV, query-range chunks per key tile)
+    against the fp32 reference, and bit-reproducible; head_dim 64 (the shapes only exist there)."""
+    hd = 64
+    M, ld, qkv, seg_s, seg_e = _attn_case(seg_lens, nH, nKV, seed=len(seg_lens), hd=hd)
+    d_o = rnd(M, nH * hd, seed=9)
+    key = (tuple(seg_lens), nH, nKV)
+    if key not in _ATTN_REF_CACHE:
+        _ATTN_REF_CACHE[key] = _attn_ref(qkv, seg_s, nH, nKV, d_o, hd=hd)
+    o_ref, dqkv_ref = _ATTN_REF_CACHE[key]
+    qd, dod = dev_bf16(qkv), dev_bf16(d_o)
+    o = torch.empty(M, nH * hd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(nH * M, dtype=torch.float32, device="cuda")
+    ss, se = seg_s.cuda(), seg_e.cuda()
+    L = lib()
+    try:
+        for k, v in (("attn_jq", jq), ("attn_kw", kw), ("attn_nch", nch)):
+            assert L.slam_set_option(None, k.encode(), v) == 0
+        assert L.slam_op_attn_fwd(ptr(qd), ptr(o), ptr(lse), ptr(ss), M, nH, nKV, hd, stream()) == 0
+        ws = torch.empty(L.slam_op_attn_bwd_workspace(M, nH, hd) // 4 + 16, dtype=torch.float32, device="cuda")
+        outs = []
+        for _ in range(2):
+            dqkv = torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert L.slam_op_attn_bwd(ptr(qd), ptr(o), ptr(dod), ptr(lse), ptr(dqkv), ptr(ws), ptr(ss), ptr(se),
+                                      M, nH, nKV, hd, stream()) == 0
+            sync()
+            outs.append(dqkv)
+    finally:
+        for k, v in (("attn_jq", 1), ("attn_kw", 1), ("attn_nch", 4)):
+            L.slam_set_option(None, k.encode(), v)
+    assert torch.equal(outs[0], outs[1]), "attention backward is not bit-reproducible"
+    got = outs[0].float().cpu()
+    check("attn bwd dq", got[:, : nH * hd], dqkv_ref[:, : nH * hd], 1.5e-2, 6e-2)
+    check("attn bwd dk", got[:, nH * hd: (nH + nKV) * hd], dqkv_ref[:, nH * hd: (nH + nKV) * hd], 1.5e-2, 6e-2)
+    check("attn bwd dv", got[:, (nH + nKV) * hd:], dqkv_ref[:, (nH + nKV) * hd:], 1.5e-2, 6e-2)
+
+
 # --------------------------------------------------------------------------------- cross entropy
 @pytest.mark.parametrize("V,Vp", [(502, 512), (700, 768), (5003, 5120)])
 @pytest.mark.parametrize("num_items", [0.0, 57.0])
