@@ -431,6 +431,10 @@ def main():
         print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if os.environ.get("SLAM_BENCH_STREAM", "0") == "1" or int(os.environ.get("SLAM_BWD_WGRAD_CUS", "0")) > 0:
+        # run the step on a non-default (non-blocking) stream: a CU-masked wgrad stream is a BLOCKING stream that would
+        # otherwise synchronise with every launch on the NULL stream (include/slam_engine.h, "bwd_wgrad_cus")
+        torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

@@ -54,7 +54,7 @@ struct AttnArgs {
   const float* rope_cs;  // nullable fp32 [M][D/2]: fold the transpose RoPE rotation into the dq / dk stores
   const float* rope_sn;
   const int* perm;     // nullable: block rank -> q tile index, heaviest tiles first; dK/dV: item list
-  int M, nH, nKV, ldq, nch;
+  int M, nH, nKV, ldq, nch, prio;
   float scale;         // head_dim^-0.5
 };
 
@@ -163,6 +163,15 @@ SLAM_DEVICE BlockItem block_item(int b, int ntile, int nH, int nKV) {
   it.h = it.kvh * G + seq % G;
   return it;
 }
+// Wave priority by LPT rank ("attn_prio"): the blocks of a launch differ 1:16 in length and the longest one IS the
+// critical path when three blocks share a CU - the heaviest quarter of the items runs at s_setprio 3, the lightest at 0,
+// so a long block is slowed less by its co-resident short ones.
+SLAM_DEVICE void set_rank_prio(int rank, int total) {
+  const int q = (4 * rank) / (total > 0 ? total : 1);
+  if (q <= 0) __builtin_amdgcn_s_setprio(3);
+  else if (q == 1) __builtin_amdgcn_s_setprio(2);
+  else if (q == 2) __builtin_amdgcn_s_setprio(1);
+}
 inline int item_grid(int ntile, int nH, int nKV) { return ((ntile * nKV + 7) / 8) * 8 * (nH / nKV); }
 
 // ------------------------------------------------------------------------------------------
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   if (!bi.valid) return;
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * 128;
+  if (p.prio && p.perm) set_rank_prio(bi.slot, (M + 127) / 128);
   const int qw0 = q0 + wave * 32;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
   if (!bi.valid) return;
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * QT;
+  if (p.prio && p.perm) set_rank_prio(bi.slot, (M + QT - 1) / QT);
   const int qw0 = q0 + wave * WR;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
@@ -573,6 +584,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
   const int kvh = blockIdx.x % p.nKV;
   const int item = p.perm[blockIdx.x / p.nKV];
   if (item < 0) return;  // the item list is sorted by work: invalid (key tile, chunk) candidates sit at its end
+  if (p.prio) set_rank_prio(blockIdx.x / p.nKV, ((M + KT - 1) / KT) * NCH_MAX);
   const int chunk = item & (NCH_MAX - 1), k0 = (item >> 2) * KT;
   const DkvRange rg = dkv_range(p.seg_end, M, k0, KT, p.nch, chunk);
   const int nq = rg.nq, qa = rg.qa;
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int* __restrict__
 
 namespace slam {
 
-static AttnTune g_attn_tune = {1, 1, 4};
+static AttnTune g_attn_tune = {1, 1, 4, 0};
 AttnTune attn_default_tune() { return g_attn_tune; }
 void attn_set_default_tune(AttnTune t) { g_attn_tune = t; }
 static AttnTune clamp_tune(AttnTune t, int head_dim) {
@@ -867,11 +879,11 @@ static int attn_dkv_launch(AttnArgs a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH,
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, AttnTune tune, int M, int nH,
              int nKV, int head_dim, hipStream_t st) {
   if ((head_dim != 64 && head_dim != 128) || nH % nKV) return -1;
   AttnArgs a{};
-  a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start; a.perm = plan;
+  a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start; a.perm = plan; a.prio = tune.prio;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);
   return head_dim == 64 ? attn_fwd_nd<1>(a, st) : attn_fwd_nd<2>(a, st);
 }
@@ -891,7 +903,7 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
   a.seg_start = seg_start; a.seg_end = seg_end;
   a.rope_cs = rope_cs; a.rope_sn = rope_sn;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);
-  a.nch = tune.nch;
+  a.nch = tune.nch; a.prio = tune.prio;
   const int nf = (M + 127) / 128, qt = 64 * tune.jq, kt = 64 * tune.kw;
   a.perm = plan + nf;
   int e;

@@ -81,6 +81,12 @@ struct SlamEngine {
   AttnTune attn_tune = attn_default_tune();
   int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
   hipStream_t wside = nullptr;
+  // "bwd_wgrad_cus" > 0: the wgrad stream is created with a CU mask of that many CUs (the low bits of the mask: on gfx950
+  // bit i is XCD i % 8, shader engine (i / 8) % 4, CU i / 32 - a prefix of 32 k bits is k CUs in every shader engine of every
+  // XCD), so that the dgrad / attention / RMSNorm chain on the caller's stream always finds CUs the background GEMMs cannot
+  // occupy. hipExtStreamCreateWithCUMask makes a BLOCKING stream: it synchronises implicitly with the NULL stream, so the
+  // caller must then run the step on a non-default stream (the trainer and bench.py do when the option is set).
+  int wside_cus = 0, wside_cus_applied = 0;
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
@@ -229,13 +235,29 @@ int ensure_side(SlamEngine* h) {
   return 0;
 }
 int ensure_wside(SlamEngine* h) {
-  if (h->wside) return 0;
-  hipError_t e = hipStreamCreateWithFlags(&h->wside, hipStreamNonBlocking);
+  if (h->wside && h->wside_cus_applied == h->wside_cus) return 0;
+  hipError_t e;
+  if (h->wside) {  // the mask changed: replace the stream
+    (void)hipStreamSynchronize(h->wside);
+    (void)hipStreamDestroy(h->wside);
+    h->wside = nullptr;
+  }
+  if (h->wside_cus > 0) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int n = h->wside_cus > 256 ? 256 : h->wside_cus;
+    for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
+    e = hipExtStreamCreateWithCUMask(&h->wside, 8, mask);
+  } else {
+    e = hipStreamCreateWithFlags(&h->wside, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) return (int)e;
-  h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
-  for (auto& ev : h->ev_w) {
-    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) return (int)e;
+  h->wside_cus_applied = h->wside_cus;
+  if (h->ev_w.empty()) {
+    h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
+    for (auto& ev : h->ev_w) {
+      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   return 0;
 }
@@ -375,16 +397,17 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "gemm_tn_bal_bg_max_split")) { gemm_set_tn_bal_bg_max_split((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224_bg_min_m")) { gemm_set_tn224_bg_min_m((int)value); return SLAM_OK; }
   if (!strcmp(key, "gemm_tn224_bg_max_split")) { gemm_set_tn224_bg_max_split((int)value); return SLAM_OK; }
-  if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch")) {
+  if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch") || !strcmp(key, "attn_prio")) {
     // with an engine: that engine's launches (takes effect at its next forward, which rebuilds the attention plan);
     // without: the process default picked up by the single-op entry points and by engines created afterwards
     AttnTune t = h ? h->attn_tune : attn_default_tune();
-    (key[5] == 'j' ? t.jq : key[5] == 'k' ? t.kw : t.nch) = (int)value;
+    (key[5] == 'j' ? t.jq : key[5] == 'k' ? t.kw : key[5] == 'n' ? t.nch : t.prio) = (int)value;
     if (h) { h->attn_tune = t; h->have_fwd = false; } else attn_set_default_tune(t);
     return SLAM_OK;
   }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -430,7 +453,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
       CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
       CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, d.head_dim, h->cosb, h->sinb, 0, st));
     }
-    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, M, nH, nKV, d.head_dim, st));
+    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, h->attn_tune, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
     CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
     if (h->fuse_swiglu) {
@@ -740,7 +763,7 @@ int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s
 }
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
                      int head_dim, slam_stream_t s) {
-  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
+  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, attn_default_tune(), M, nH, nKV, head_dim, (hipStream_t)s);
 }
 size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim) {
   // the ABI call has no KV-head count: sized for nKV = nH (plain multi-head attention), the largest case

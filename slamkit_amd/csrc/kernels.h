@@ -47,13 +47,13 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
 // attention.hip
 // launch-shape choices of the backward kernels (engine-owned, "attn_jq" / "attn_kw" / "attn_nch" options):
 // jq / kw = 16-row fragments per wave in dQ / dK-dV (1 or 2; head_dim 64 only), nch = query-range chunks per key tile (1..4)
-struct AttnTune { int jq, kw, nch; };
+struct AttnTune { int jq, kw, nch, prio; };  // prio: s_setprio by LPT rank (0 = off)
 AttnTune attn_default_tune();
 void attn_set_default_tune(AttnTune t);
 size_t attn_plan_ints(int M);
 int attn_plan(const int* seg_start, const int* seg_end, int M, int head_dim, AttnTune tune, int* plan, hipStream_t st);
-int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, int M, int nH, int nKV,
-             int head_dim, hipStream_t st);
+int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, const int* plan, AttnTune tune, int M, int nH,
+             int nKV, int head_dim, hipStream_t st);
 size_t attn_bwd_workspace_bytes(int M, int nKV, int head_dim);
 // rope_cs / rope_sn (nullable): fp32 [M][head_dim/2] tables; when given, dq and dk are written already
 // rotated back (transpose rotation), i.e. as gradients of the pre-RoPE projections. plan (required) must come from
