@@ -135,6 +135,36 @@ int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp
 int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out, double lr,
                          double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t zero_grad,
                          slam_stream_t stream);
+/* ---- sharded optimizer step: the data-parallel "rs_ag" exchange (replaces torch DDP's all-reduce of
+ * every gradient followed by N identical optimizer steps, /root/reference config/training_args/default.yaml:18 +
+ * site-packages transformers/trainer.py) -------------------------------------------------------------------------------
+ * Per gradient bucket the ranks reduce-scatter the gradients, each rank updates the 1/N shard it owns, and the bf16
+ * parameters are all-gathered while the next forward already runs. The global gradient norm is defined on fixed chunks of
+ * slam_grad_chunk_elems() consecutive elements of the flat buffer: slam_grad_sumsq_chunks fills chunk_sums[k] (fp32
+ * [ceil(slam_param_count / chunk)], device) for the chunk-aligned range it is given - a rank fills the chunks of its own
+ * shards and leaves zeros elsewhere, the arrays are summed over the ranks (exact: disjoint support), and
+ * slam_grad_norm_from_chunks finishes {norm, clip coefficient} exactly as slam_grad_norm does for the whole buffer (which
+ * computes the same chunk sums itself): the sharded and the replicated step clip with bit-identical coefficients. */
+int64_t slam_grad_chunk_elems(void);
+int slam_grad_sumsq_chunks(SlamEngine* h, int64_t offset, int64_t count, float* chunk_sums, slam_stream_t stream);
+int slam_grad_norm_from_chunks(SlamEngine* h, const float* chunk_sums, float max_norm, float* norm_out, slam_stream_t stream);
+/* slam_adamw_step on elements [offset, offset + count) only (multiples of 4; 8 for the bf16-state form): master / exp_avg /
+ * exp_avg_sq point at THE RANGE'S first element (compact per-shard storage or base + offset of full-size buffers). Does not
+ * refresh the transposed weight images: the next slam_backward does, after every pending parameter write has landed. */
+int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master_f32, float* exp_avg, float* exp_avg_sq,
+                     const float* norm_out, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     int32_t step, int32_t zero_grad, slam_stream_t stream);
+int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                          const float* norm_out, double lr, double beta1, double beta2, double eps, double weight_decay,
+                          int32_t step, int32_t zero_grad, slam_stream_t stream);
+/* Another stream (the all-gather of a parameter bucket) is still writing the bound bf16 parameters in [offset, offset +
+ * count); `event` (hipEvent_t, owned by the caller, alive until the next forward was enqueued) is recorded behind that
+ * write. The next slam_forward waits for it right before its first read of the range - layer by layer, so the gather of
+ * the later layers runs under the first layers' kernels; every other entry point that touches parameters waits for all
+ * of them first. slam_param_wait_ms: total stall of the caller's stream in those waits since the last query (host-
+ * synchronising: logging only). */
+int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event);
+int slam_param_wait_ms(SlamEngine* h, float* total_ms);
 /* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
  * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
  * joins first. slam_join makes `stream` wait for a pending update before the caller touches the parameter, gradient or
@@ -144,7 +174,10 @@ int slam_zero_grads(SlamEngine* h, slam_stream_t stream);
 int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t stream); /* fp32 -> bound bf16 */
 
 /* ---- tuning knobs ---------------------------------------------------------------------------*/
-/* Tuning / mode switches. "grad_overwrite_next" = 1: the next slam_backward stores the gradients instead of adding to
+/* Tuning / mode switches. "attn_jq" / "attn_kw" (1 or 2: 16-row fragments per wave in the attention dQ / dK-dV kernels), "attn_nch" (1..4 query-range
+ * chunks per key tile), "attn_prio" (wave priority by block length); with h = NULL they set the process default used by the
+ * single-op entry points. "bwd_wgrad_cus" = N > 0: the weight-gradient stream is created with a CU mask of N CUs (a BLOCKING
+ * stream: run the step on a non-default stream then). "grad_overwrite_next" = 1: the next slam_backward stores the gradients instead of adding to
  * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "bwd_wgrad_stream" (default
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every

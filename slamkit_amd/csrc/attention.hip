@@ -84,17 +84,21 @@ struct TileOff {
     return (uint32_t)(((size_t)row * ld + c * 8) * sizeof(bf16_t));
   }
 };
-SLAM_DEVICE void dma_tile64(const bf16_t* base, const TileOff& to, int row0, int M, int wave, uint32_t img) {
-  const bf16_t* tb = base + (size_t)row0 * to.ld;  // wave-uniform
-  if (row0 + 64 <= M) {
+// LDS-DMA with the LDS destination in M0 as an inline-asm register constraint: the compiler materialises each
+// destination with ONE s_mov / s_add into m0 (round 2 saved and restored m0 around every load: 4 SALU per DMA, 32 per
+// forward tile - a wave issues about one instruction per 7 cycles, so scalar bookkeeping is not free).
+SLAM_DEVICE void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
+}
+SLAM_DEVICE void glds4_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
+}
+// one 64x64 tile whose first row is at `tb` (wave-uniform) -> image at LDS address `dst` (this wave's 1 KB slice of each
+// 4 KB half); maxrow >= 63: every row exists (tile-invariant offsets), else rows are clamped to maxrow
+template <bool FULL>
+SLAM_DEVICE void dma_tile64(const bf16_t* tb, const TileOff& to, int maxrow, uint32_t dst) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16_sv(tb, to.v[i], __builtin_amdgcn_readfirstlane(img + (uint32_t)(i * 256 + wave * 64) * 16u));
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16_sv(tb, to.off(i, M - 1 - row0), __builtin_amdgcn_readfirstlane(img + (uint32_t)(i * 256 + wave * 64) * 16u));
-  }
+  for (int i = 0; i < 2; ++i) glds16_m0(tb, FULL ? to.v[i] : to.off(i, maxrow), dst + (uint32_t)(i * 4096));
 }
 
 // Per-lane fragment offsets inside a unified image (tile-invariant); TileAddr = the same re-based on a stage, once per
@@ -210,17 +214,33 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   FragOff fo;
   fo.init(l15, g);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  auto issue = [&](int t, int stage) {
-    const uint32_t st = lds0 + (uint32_t)(stage * STG);
+  // running tile pointers (wave-uniform): one 64-bit add per operand per tile
+  const size_t tstep = (size_t)64 * ld;
+  const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
+  const bf16_t* vp = Vb + (size_t)kt_begin * tstep;
+  int irow = kt_begin * 64;
+  const uint32_t wdst = lds0 + (uint32_t)wv * 1024u;
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    const uint32_t st = wdst + (uint32_t)(stage * STG);
+    if (irow + 64 <= M) {  // ONE wave-uniform branch per tile
 #pragma unroll
-    for (int dh = 0; dh < ND; ++dh) {
-      dma_tile64(Kb + dh * 64, off, (kt_begin + t) * 64, M, wv, st + dh * IMG);
-      dma_tile64(Vb + dh * 64, off, (kt_begin + t) * 64, M, wv, st + (ND + dh) * IMG);
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<true>(kp + dh * 64, off, 63, st + dh * IMG);
+        dma_tile64<true>(vp + dh * 64, off, 63, st + (ND + dh) * IMG);
+      }
+    } else {
+      const int mr = M - 1 - irow;
+#pragma unroll
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<false>(kp + dh * 64, off, mr, st + dh * IMG);
+        dma_tile64<false>(vp + dh * 64, off, mr, st + (ND + dh) * IMG);
+      }
     }
+    kp += tstep; vp += tstep; irow += 64;
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < n) issue(s, s);
+    if (s < n) issue(s);
 
   int qrow[2], segs[2];
   uint4 qf[2][2 * ND];
@@ -249,7 +269,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
     if (NST >= 3 && t + 1 < n) wait_vmcnt<4 * ND>();
     else wait_vmcnt<0>();
     __syncthreads();
-    if (t + NST - 1 < n) issue(t + NST - 1, istage);
+    if (t + NST - 1 < n) issue(istage);
     istage = istage + 1 == NST ? 0 : istage + 1;
     const uint32_t sb = lds0 + (uint32_t)(stage * STG);
     stage = stage + 1 == NST ? 0 : stage + 1;
@@ -397,18 +417,32 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
   FragOff fo;
   fo.init(l15, g);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  auto issue = [&](int t, int stage) {
-    const uint32_t st = lds0 + (uint32_t)(stage * STG);
-    const int r0 = (kt_begin + t) * 64;
+  const size_t tstep = (size_t)64 * ld;
+  const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
+  const bf16_t* vp = Vb + (size_t)kt_begin * tstep;
+  int irow = kt_begin * 64;
+  const uint32_t wdst = lds0 + (uint32_t)wv * 1024u;
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    const uint32_t st = wdst + (uint32_t)(stage * STG);
+    if (irow + 64 <= M) {  // ONE wave-uniform branch per tile
 #pragma unroll
-    for (int dh = 0; dh < ND; ++dh) {
-      dma_tile64(Kb + dh * 64, off, r0, M, wv, st + dh * IMG);
-      dma_tile64(Vb + dh * 64, off, r0, M, wv, st + (ND + dh) * IMG);
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<true>(kp + dh * 64, off, 63, st + dh * IMG);
+        dma_tile64<true>(vp + dh * 64, off, 63, st + (ND + dh) * IMG);
+      }
+    } else {
+      const int mr = M - 1 - irow;
+#pragma unroll
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<false>(kp + dh * 64, off, mr, st + dh * IMG);
+        dma_tile64<false>(vp + dh * 64, off, mr, st + (ND + dh) * IMG);
+      }
     }
+    kp += tstep; vp += tstep; irow += 64;
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < n) issue(s, s);
+    if (s < n) issue(s);
 
   int qrow[JQ], segs[JQ];
   float lse[JQ], nds[JQ];
@@ -450,7 +484,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
     if (NST >= 3 && t + 1 < n) wait_vmcnt<4 * ND>();
     else wait_vmcnt<0>();
     __syncthreads();
-    if (t + NST - 1 < n) issue(t + NST - 1, istage);
+    if (t + NST - 1 < n) issue(istage);
     istage = istage + 1 == NST ? 0 : istage + 1;
     const uint32_t sb = lds0 + (uint32_t)(stage * STG);
     stage = stage + 1 == NST ? 0 : stage + 1;
@@ -479,7 +513,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
         }
       }
     uint4 dsb[2][JQ];
-    auto soft = [&](auto mk) {
+    auto soft = [&](auto mk) __attribute__((always_inline)) {
       constexpr bool MASK = decltype(mk)::value;
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
@@ -599,25 +633,41 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
   FragOff fo;
   fo.init(l15, g);
 
-  int i_hq = 0, i_tq = 0, istage = 0;  // next tile to issue: (head in group, query tile in chunk), wave-uniform
-  auto issue_next = [&]() {
-    const uint32_t st = lds0 + (uint32_t)(istage * STG);
-    const int h = kvh * G + i_hq;
-    const int r0 = (qa + i_tq) * 64;
-    const bf16_t* Qb = p.qkv + h * D;
-    const bf16_t* dOb = p.d_o + h * D;
+  // next tile to issue: running pointers of the (head, query tile) walk, all wave-uniform
+  const size_t qstep = (size_t)64 * ld, ostep = (size_t)64 * ldo;
+  const bf16_t* qp = p.qkv + (size_t)(kvh * G) * D + (size_t)qa * qstep;
+  const bf16_t* dop = p.d_o + (size_t)(kvh * G) * D + (size_t)qa * ostep;
+  int i_tq = 0, i_head = kvh * G, istage = 0, irow = qa * 64;
+  const uint32_t wdst = lds0 + (uint32_t)wv * 1024u, sdst = lds0 + (uint32_t)(2 * ND * IMG) + (uint32_t)wv * 256u;
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    const uint32_t st = wdst + (uint32_t)(istage * STG);
+    const int mr = irow + 64 <= M ? 63 : M - 1 - irow;
+    if (mr >= 63) {  // ONE wave-uniform branch per tile
 #pragma unroll
-    for (int dh = 0; dh < ND; ++dh) {
-      dma_tile64(Qb + dh * 64, qoff, r0, M, wv, st + dh * IMG);
-      dma_tile64(dOb + dh * 64, ooff, r0, M, wv, st + (ND + dh) * IMG);
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<true>(qp + dh * 64, qoff, 63, st + dh * IMG);
+        dma_tile64<true>(dop + dh * 64, ooff, 63, st + (ND + dh) * IMG);
+      }
+    } else {
+#pragma unroll
+      for (int dh = 0; dh < ND; ++dh) {
+        dma_tile64<false>(qp + dh * 64, qoff, mr, st + dh * IMG);
+        dma_tile64<false>(dop + dh * 64, ooff, mr, st + (ND + dh) * IMG);
+      }
     }
     // per-row scalars: wave 0 -> lse2, 1 -> -D, 2 -> seg_start, 3 -> spare slot (keeps the DMA count uniform)
-    const int row = min(r0 + lane, M - 1);
-    const void* src = wv == 0 ? (const void*)(p.lse2 + (size_t)h * M + row)
-                    : wv == 1 ? (const void*)(p.ndsum + (size_t)h * M + row)
-                              : (const void*)(p.seg_start + row);
-    glds4(src, __builtin_amdgcn_readfirstlane(st + 2 * ND * IMG + (uint32_t)wv * 256u));
-    if (++i_tq == nq) { i_tq = 0; ++i_hq; }
+    // (the three sources are chosen from loop-invariant bases: a select between loop-carried pointers becomes a lookup
+    //  table in scratch memory, and scratch traffic would also break the counted vmcnt waits)
+    const size_t hrow = (size_t)i_head * M + irow;
+    const void* src = wv == 0 ? (const void*)(p.lse2 + hrow) : wv == 1 ? (const void*)(p.ndsum + hrow) : (const void*)(p.seg_start + irow);
+    glds4_m0(src, (uint32_t)(lane < mr ? lane : mr) * 4u, sdst + (uint32_t)(istage * STG));
+    qp += qstep; dop += ostep; irow += 64;
+    if (++i_tq == nq) {  // next head of the group: back to the chunk's first query tile
+      i_tq = 0;
+      ++i_head;
+      qp += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)qstep; dop += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)ostep;
+      irow -= nq * 64;
+    }
     istage = istage + 1 == NST ? 0 : istage + 1;
   };
 #pragma unroll
@@ -680,7 +730,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
       }
     // lane holds (q = qbase + jq*16 + 4g + r, key[i]); mask only on diagonal / segment-boundary / tail tiles
     uint4 pb[2][KW], dsb[2][KW];
-    auto soft = [&](auto mk) {
+    auto soft = [&](auto mk) __attribute__((always_inline)) {
       constexpr bool MASK = decltype(mk)::value;
       int lo[KW], mh = 0;
       if constexpr (MASK) {
@@ -795,7 +845,7 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int* __restrict__
   // one block: phase 1 writes every candidate's work into LDS, phase 2 ranks it inside its own list
   extern __shared__ int wk[];
   const int nf = (M + 127) / 128, nq = (M + qt - 1) / qt, nk = (M + kt - 1) / kt;
-  const int total = nf + nq + nk * NCH_MAX;
+  const int total = seg_e ? nf + nq + nk * NCH_MAX : nf;  // seg_e == NULL: forward order only
   for (int t = threadIdx.x; t < total; t += blockDim.x) {
     int w;
     if (t < nf) { int q0 = t * 128; w = min(q0 + 127, M - 1) / 64 - seg_s[q0] / 64 + 1; }

@@ -647,19 +647,29 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x,
 
 // ------------------------------------------------------------------------------------------
 // Gradient norm (fp32 flat buffer) -> clip coefficient, and fused AdamW.
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n,
-                                                            float* __restrict__ part) {
+// Canonical chunked sum of squares: chunk k = elements [k C, (k+1) C) of the flat gradient buffer (absolute positions,
+// C = GRAD_CHUNK), one block per chunk, fixed summation order inside it. Any partition of the buffer into chunk-aligned
+// ranges - the whole buffer on one GPU, one 1/N shard per bucket per rank under the sharded optimizer - produces the
+// same chunk sums bit for bit; norm_finish_kernel adds them in fp64 in chunk order.
+constexpr int GRAD_CHUNK = 8192;
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, size_t n, size_t first_chunk,
+                                                           float* __restrict__ chunk_sums) {
   __shared__ float red[4];
+  const size_t k = first_chunk + blockIdx.x;
+  const size_t lo = k * GRAD_CHUNK, hi = lo + GRAD_CHUNK < n ? lo + GRAD_CHUNK : n;
   float s = 0.f;
-  size_t stride = (size_t)gridDim.x * 256 * 4;
-  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-    float4 v = *reinterpret_cast<const float4*>(g + i);
-    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int it = 0; it < GRAD_CHUNK / 1024; ++it) {
+    const size_t i = lo + (size_t)(it * 256 + threadIdx.x) * 4;
+    if (i < hi) {
+      float4 v = *reinterpret_cast<const float4*>(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) chunk_sums[k] = red[0] + red[1] + red[2] + red[3];
 }
 // out[0] = ||g||, out[1] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 when max_norm<=0)
 __global__ void norm_finish_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
@@ -925,12 +935,22 @@ int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st) {
   LAUNCH_RET();
 }
 
-int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st) {
-  if (n & 3) return -1;
-  int nb = 1024;
-  sumsq_partial_kernel<<<nb, 256, 0, st>>>(g, n, part);
-  norm_finish_kernel<<<1, 256, 0, st>>>(part, nb, max_norm, out);
+int grad_chunk_elems() { return GRAD_CHUNK; }
+// chunk sums of the chunk-aligned range [off, off + cnt) (cnt may end at n instead of a chunk boundary)
+int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st) {
+  if ((n & 3) || (off % GRAD_CHUNK) || off + cnt > n || (((off + cnt) % GRAD_CHUNK) && off + cnt != n)) return -1;
+  if (cnt == 0) return 0;
+  const size_t nb = (cnt + GRAD_CHUNK - 1) / GRAD_CHUNK;
+  sumsq_chunks_kernel<<<(unsigned)nb, 256, 0, st>>>(g, n, off / GRAD_CHUNK, chunk_sums);
   LAUNCH_RET();
+}
+int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st) {
+  norm_finish_kernel<<<1, 256, 0, st>>>(chunk_sums, (int)n_chunks, max_norm, out);
+  LAUNCH_RET();
+}
+int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st) {
+  if (int r = grad_sumsq_chunks(g, n, 0, n, part, st)) return r;
+  return grad_norm_from_chunks(part, (n + GRAD_CHUNK - 1) / GRAD_CHUNK, max_norm, out, st);
 }
 int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
           double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {

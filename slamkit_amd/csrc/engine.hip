@@ -96,7 +96,15 @@ struct SlamEngine {
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pw_ev) (void)hipEventDestroy(e);
   }
+  // parameter ranges another stream is still writing (sharded optimizer: the bf16 parameter all-gather on the
+  // communication stream): the next reader waits for the event right before its first read of the range
+  struct ParamWait { int64_t lo, hi; hipEvent_t ev; };
+  std::vector<ParamWait> pwaits;
+  std::vector<hipEvent_t> pw_ev;   // timing pairs around the waits (exposed all-gather time), reused step after step
+  size_t pw_used = 0;
+  bool params_t_dirty = false;     // ranged optimizer updates leave the transposed weight images stale until backward needs them
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -190,6 +198,8 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
   if (part2 > part) part = part2;
   if (part < 1024) part = 1024;
+  const size_t n_chunks = ((size_t)e->n_params + grad_chunk_elems() - 1) / grad_chunk_elems();  // gradient-norm chunk sums
+  if (part < n_chunks) part = n_chunks;
   e->part_ws = c.take<float>(part);
   e->ln_ps = (size_t)rmsnorm_bwd_blocks((int)M) * H;
   e->bias_ps = (size_t)colsum_blocks((int)M) * e->QKV;
@@ -273,11 +283,38 @@ int join_optimizer(SlamEngine* h, hipStream_t st) {
   return (int)hipStreamWaitEvent(st, h->ev_chunk.back(), 0);
 }
 
+// make `st` wait for the pending writers of parameters in [lo, hi); the stall is bracketed by two timing events
+int wait_params(SlamEngine* h, int64_t lo, int64_t hi, hipStream_t st) {
+  for (size_t i = 0; i < h->pwaits.size();) {
+    SlamEngine::ParamWait& w = h->pwaits[i];
+    if (w.lo < hi && lo < w.hi) {
+      if (h->pw_used + 2 > h->pw_ev.size()) {
+        for (int k = 0; k < 2; ++k) {
+          hipEvent_t e;
+          hipError_t r = hipEventCreate(&e);
+          if (r != hipSuccess) return (int)r;
+          h->pw_ev.push_back(e);
+        }
+      }
+      hipError_t r = hipEventRecord(h->pw_ev[h->pw_used], st);
+      if (r == hipSuccess) r = hipStreamWaitEvent(st, w.ev, 0);
+      if (r == hipSuccess) r = hipEventRecord(h->pw_ev[h->pw_used + 1], st);
+      if (r != hipSuccess) return (int)r;
+      h->pw_used += 2;
+      h->pwaits.erase(h->pwaits.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+  return 0;
+}
+int join_params(SlamEngine* h, hipStream_t st) { return h->pwaits.empty() ? 0 : wait_params(h, 0, h->n_params, st); }
+
 }  // namespace
 
 extern "C" {
 
-const char* slam_version(void) { return "slam-engine gfx950 r2"; }
+const char* slam_version(void) { return "slam-engine gfx950 r3"; }
 
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
@@ -334,6 +371,8 @@ int slam_refresh_transposed(SlamEngine* h, slam_stream_t stream) {
   if (!h->params) return h->fail(SLAM_ESTATE, "bind params first");
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
+  CK(join_params(h, st));
+  h->params_t_dirty = false;
   const SlamModelDesc& d = h->d;
   const bf16_t* P = h->params;
   bf16_t* Pt = h->params_t;
@@ -363,6 +402,7 @@ size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens) {
   tmp.d = h->d;
   tmp.QKV = h->QKV;
   tmp.vpad = h->vpad;
+  tmp.n_params = h->n_params;
   return carve(&tmp, nullptr, max_tokens);
 }
 int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_tokens) {
@@ -441,11 +481,13 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
   CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, d.head_dim, h->attn_tune, h->attn_plan_buf, st));
   CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
   CK(wait_chunk(h, 0, st));
+  CK(wait_params(h, h->off_embed, h->lo[0].ln1, st));
   CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
   for (int l = 0; l < L; ++l) {
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
     CK(wait_chunk(h, 1 + l, st));
+    CK(wait_params(h, o.ln1, o.ln1 + h->layer_stride, st));
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
     if (d.head_dim == 64 && (H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
       CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, nH + nKV, M, h->QKV, H, st));
@@ -465,6 +507,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
   CK(join_optimizer(h, st));
+  CK(join_params(h, st));
   CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
   const int VP = h->vpad;
   CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
@@ -491,6 +534,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   const SlamModelDesc& d = h->d;
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
+  CK(join_params(h, st));
+  if (h->params_t_dirty) CK(slam_refresh_transposed(h, stream));
   const int M = h->B * h->T;
   const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
   const int HD = nH * d.head_dim;
@@ -651,6 +696,7 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
   if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
+  CK(join_params(h, st));
   if (!h->overlap_adamw) {
     CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
     return slam_refresh_transposed(h, stream);
@@ -696,9 +742,77 @@ int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf1
   return slam_refresh_transposed(h, stream);
 }
 
+// ---- sharded optimizer (data-parallel "rs_ag": reduce-scatter gradients, update the owned 1/N shard, all-gather bf16
+// parameters) ------------------------------------------------------------------------------------------------------
+int64_t slam_grad_chunk_elems(void) { return grad_chunk_elems(); }
+
+int slam_grad_sumsq_chunks(SlamEngine* h, int64_t offset, int64_t count, float* chunk_sums, slam_stream_t stream) {
+  if (!h || !chunk_sums || offset < 0 || count < 0) return SLAM_EINVAL;
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  int r = grad_sumsq_chunks(h->grads, (size_t)h->n_params, (size_t)offset, (size_t)count, chunk_sums, (hipStream_t)stream);
+  if (r < 0) return h->fail(SLAM_EINVAL, "range must start on a chunk boundary and end on one (or at the end of the buffer)");
+  CK(r);
+  return SLAM_OK;
+}
+
+int slam_grad_norm_from_chunks(SlamEngine* h, const float* chunk_sums, float max_norm, float* norm_out, slam_stream_t stream) {
+  if (!h || !chunk_sums || !norm_out) return SLAM_EINVAL;
+  const size_t nc = ((size_t)h->n_params + grad_chunk_elems() - 1) / grad_chunk_elems();
+  CK(grad_norm_from_chunks(chunk_sums, nc, max_norm, norm_out, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master, float* m, float* v, const float* norm_out,
+                     double lr, double b1, double b2, double eps, double wd, int32_t step, int32_t zero_grad,
+                     slam_stream_t stream) {
+  if (!h || !master || !m || !v || step < 1 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3))
+    return SLAM_EINVAL;
+  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
+  if (count)
+    CK(adamw(master, h->params + offset, h->grads + offset, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+  h->params_t_dirty = h->params_t != nullptr;
+  return SLAM_OK;
+}
+
+int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* m_bf16, void* v_bf16, const float* norm_out,
+                          double lr, double b1, double b2, double eps, double wd, int32_t step, int32_t zero_grad,
+                          slam_stream_t stream) {
+  if (!h || !m_bf16 || !v_bf16 || step < 1 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 7) || (count & 7))
+    return SLAM_EINVAL;
+  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
+  if (count)
+    CK(adamw_bf16(h->params + offset, h->grads + offset, (bf16_t*)m_bf16, (bf16_t*)v_bf16, (size_t)count, norm_out, lr, b1, b2, eps,
+                  wd, step, zero_grad, st));
+  h->params_t_dirty = h->params_t != nullptr;
+  return SLAM_OK;
+}
+
+int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event) {
+  if (!h || !event || offset < 0 || count <= 0 || offset + count > h->n_params) return SLAM_EINVAL;
+  h->pwaits.push_back({offset, offset + count, (hipEvent_t)event});
+  return SLAM_OK;
+}
+
+int slam_param_wait_ms(SlamEngine* h, float* total_ms) {
+  if (!h || !total_ms) return SLAM_EINVAL;
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < h->pw_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventSynchronize(h->pw_ev[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->pw_ev[i], h->pw_ev[i + 1]) == hipSuccess) tot += ms;
+  }
+  h->pw_used = 0;
+  *total_ms = tot;
+  return SLAM_OK;
+}
+
 int slam_join(SlamEngine* h, slam_stream_t stream) {
   if (!h) return SLAM_EINVAL;
   CK(join_optimizer(h, (hipStream_t)stream));
+  CK(join_params(h, (hipStream_t)stream));
   return SLAM_OK;
 }
 
@@ -763,7 +877,19 @@ int slam_op_swiglu_bwd(void* gu, const void* dact, int M, int I, slam_stream_t s
 }
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
                      int head_dim, slam_stream_t s) {
-  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, nullptr, attn_default_tune(), M, nH, nKV, head_dim, (hipStream_t)s);
+  // the forward runs in the engine's heaviest-first block order; the op entry keeps a process-lifetime plan buffer for it
+  static int* plan = nullptr;
+  static size_t cap = 0;
+  const size_t need = attn_plan_ints(M);
+  if (need > cap) {
+    if (plan) (void)hipFree(plan);
+    if (hipMalloc(&plan, need * sizeof(int)) != hipSuccess) { plan = nullptr; cap = 0; return (int)hipErrorOutOfMemory; }
+    cap = need;
+  }
+  const AttnTune tune = attn_default_tune();
+  int r = attn_plan(seg_start, nullptr, M, head_dim, tune, plan, (hipStream_t)s);
+  if (r) return r;
+  return attn_fwd((const bf16_t*)qkv, (bf16_t*)o, lse2, seg_start, plan, tune, M, nH, nKV, head_dim, (hipStream_t)s);
 }
 size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim) {
   // the ABI call has no KV-head count: sized for nKV = nH (plain multi-head attention), the largest case

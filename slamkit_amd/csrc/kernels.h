@@ -87,7 +87,11 @@ int seq_loglik(const float* row_loss, const int64_t* labels, int B, int T, float
 int copy_cols(const bf16_t* src, int lds_, bf16_t* dst, int ldd, int M, int ncols, hipStream_t st);
 int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st);
 int scale_rows_bf16(bf16_t* x, const float* coef, int M, int T, int ncols, hipStream_t st);
+// part: (n + grad_chunk_elems() - 1) / grad_chunk_elems() floats
 int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st);
+int grad_chunk_elems();
+int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st);
+int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st);
 int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
           double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
 // bf16 parameters and bf16 moments updated in place (fp32 arithmetic per element, no master copy)

@@ -76,6 +76,13 @@ def load_library(path: Optional[str] = None):
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
         "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_adamw_step_bf16": (C.c_int, [vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_grad_chunk_elems": (i64, []),
+        "slam_grad_sumsq_chunks": (C.c_int, [vp, i64, i64, vp, vp]),
+        "slam_grad_norm_from_chunks": (C.c_int, [vp, vp, f32, vp, vp]),
+        "slam_adamw_range": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_adamw_range_bf16": (C.c_int, [vp, i64, i64, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_add_param_wait": (C.c_int, [vp, i64, i64, vp]),
+        "slam_param_wait_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
@@ -247,6 +254,47 @@ class Engine:
                                                float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                                int(bool(zero_grad)),
                                                stream if stream is not None else current_stream_ptr()))
+
+    # -- sharded optimizer step (data-parallel "rs_ag") ----------------------------------------------------
+    def grad_chunk_info(self):
+        """(elements per gradient-norm chunk, number of chunks of the flat buffer)."""
+        c = int(self.lib.slam_grad_chunk_elems())
+        return c, (self.n_params + c - 1) // c
+
+    def grad_sumsq_chunks(self, offset: int, count: int, chunk_sums, stream=None):
+        self._ck(self.lib.slam_grad_sumsq_chunks(self.h, int(offset), int(count), _ptr(chunk_sums),
+                                                 stream if stream is not None else current_stream_ptr()))
+
+    def grad_norm_from_chunks(self, chunk_sums, max_norm: float, norm_out, stream=None):
+        self._ck(self.lib.slam_grad_norm_from_chunks(self.h, _ptr(chunk_sums), float(max_norm), _ptr(norm_out),
+                                                     stream if stream is not None else current_stream_ptr()))
+
+    def adamw_range(self, offset: int, count: int, master, exp_avg, exp_avg_sq, norm_out, lr, beta1, beta2, eps, weight_decay,
+                    step, zero_grad=False, stream=None):
+        """AdamW on elements [offset, offset + count): master / exp_avg / exp_avg_sq are FULL-SIZE flat tensors here (the
+        range's slices are passed down); master = None selects the bf16-state form."""
+        o, n = int(offset), int(count)
+        st = stream if stream is not None else current_stream_ptr()
+        if master is None:
+            self._ck(self.lib.slam_adamw_range_bf16(self.h, o, n, _ptr(exp_avg[o:o + n]), _ptr(exp_avg_sq[o:o + n]), _ptr(norm_out),
+                                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                    int(step), int(bool(zero_grad)), st))
+        else:
+            self._ck(self.lib.slam_adamw_range(self.h, o, n, _ptr(master[o:o + n]), _ptr(exp_avg[o:o + n]), _ptr(exp_avg_sq[o:o + n]),
+                                               _ptr(norm_out), float(lr), float(beta1), float(beta2), float(eps),
+                                               float(weight_decay), int(step), int(bool(zero_grad)), st))
+
+    def add_param_wait(self, offset: int, count: int, event):
+        """event: a recorded torch.cuda.Event; kept alive here until the next forward consumed it."""
+        self._keep.setdefault("param_events", []).append(event)
+        if len(self._keep["param_events"]) > 256:
+            del self._keep["param_events"][:128]
+        self._ck(self.lib.slam_add_param_wait(self.h, int(offset), int(count), C.c_void_p(int(event.cuda_event))))
+
+    def param_wait_ms(self) -> float:
+        out = C.c_float(0.0)
+        self._ck(self.lib.slam_param_wait_ms(self.h, C.byref(out)))
+        return float(out.value)
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))

@@ -125,6 +125,120 @@ class GradBucketReducer:
         return covered
 
 
+class ShardedGradReducer(GradBucketReducer):
+    """ddp_algo = "rs_ag": the exchange SURVEY.md section 5 / 8e names for 8 GPUs on 7 point-to-point xGMI links each.
+
+    Per gradient bucket the ranks REDUCE-SCATTER the gradients (every rank ends up with the summed 1/N shard it owns:
+    each of its 7 links carries one shard concurrently), the optimizer then runs on the owned shards only (AdamW time
+    and optimizer-state traffic / N), and the updated bf16 PARAMETERS are ALL-GATHERED bucket by bucket in the order
+    the next forward needs them - the engine waits for each bucket right before its first read (slam_add_param_wait),
+    so the gather of the later layers runs under the first layers' kernels. Same bytes on the wire as a bf16
+    all-reduce of the gradients, no fp32 -> bf16 -> fp32 round trip of the whole buffer for the second half.
+
+    Buckets are the engine's reported ranges re-cut at multiples of world x grad-norm-chunk elements, so that every
+    shard is a whole number of norm chunks (the global gradient norm is then bit-identical to the replicated step:
+    include/slam_engine.h, slam_grad_sumsq_chunks). The few thousand elements above the last multiple (the top of the
+    flat buffer) stay replicated: all-reduced and updated by every rank."""
+
+    def __init__(self, flat_grads, flat_params, chunk_elems: int, group=None, comm_dtype=None):
+        super().__init__(flat_grads, group=group, comm_dtype=comm_dtype)
+        self.params = flat_params
+        self.n = flat_grads.numel()
+        w = max(1, self.world)
+        self.align = w * int(chunk_elems)
+        self.top = (self.n // self.align) * self.align   # [top, n): replicated tail
+        self.cut_hi = self.top
+        self.buckets = []   # (lo, hi) of this step's communicated buckets
+        self.owned = []     # (offset, count) this rank owns after finish()
+        self.active = False
+        self._ag_events = []
+
+    @property
+    def tail(self):
+        return (self.top, self.n - self.top)
+
+    def _on_side(self, ready_stream, fn):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(ready_stream, device=self.flat.device) if ready_stream
+                      else torch.cuda.current_stream(self.flat.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                fn()
+        else:
+            fn()
+
+    def _reduce_scatter(self, lo: int, hi: int):
+        w, r = max(1, self.world), self.rank
+        s = (hi - lo) // w
+        view = self.flat[lo:hi]
+        if self.comm_dtype is None:
+            dist.reduce_scatter_tensor(view[r * s:(r + 1) * s], view, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # cast the bucket, exchange in bf16, cast the owned shard back
+            if self.stage is None:
+                self.stage = torch.empty(self.n, dtype=self.comm_dtype, device=self.flat.device)
+            st = self.stage[lo:hi]
+            st.copy_(view)
+            dist.reduce_scatter_tensor(st[r * s:(r + 1) * s], st, op=dist.ReduceOp.SUM, group=self.group)
+            view[r * s:(r + 1) * s].copy_(st[r * s:(r + 1) * s])
+
+    def on_bucket(self, offset: int, count: int, ready_stream: Optional[int] = None):
+        self.ranges.append((offset, count))
+        if (self.world == 1 and not self.force) or count <= 0:
+            return
+        self.active = True
+        if offset + count >= self.n and self.top < self.n:  # first range of a backward: the replicated tail
+            t0 = self.top
+            self._on_side(ready_stream, lambda: dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group))
+        lo = 0 if offset == 0 else min(self.cut_hi, -(-offset // self.align) * self.align)
+        if lo < self.cut_hi:
+            hi = self.cut_hi
+            self._on_side(ready_stream, lambda: self._reduce_scatter(lo, hi))
+            self.buckets.append((lo, hi))
+            self.cut_hi = lo
+
+    def finish(self):
+        covered = super().finish() if not self.active else self._finish_active()
+        return covered
+
+    def _finish_active(self):
+        if self.side is not None:
+            cur = torch.cuda.current_stream(self.flat.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            cur.wait_stream(self.side)
+            e1.record(cur)
+            self._exposed = (e0, e1)
+        assert self.cut_hi == 0, "backward did not report the range down to offset 0"
+        w, r = max(1, self.world), self.rank
+        self.owned = [(lo + r * ((hi - lo) // w), (hi - lo) // w) for lo, hi in self.buckets]
+        self.last_buckets = list(self.buckets)
+        self.buckets, self.cut_hi, self.active = [], self.top, False
+        covered = sorted(self.ranges)
+        self.ranges = []
+        return covered
+
+    def gather_params(self, engine):
+        """All-gather the updated bf16 parameters, lowest offsets (the layers the next forward reads first) first, on
+        the communication stream; each bucket is handed to the engine as a pending parameter write."""
+        w, r = max(1, self.world), self.rank
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.flat.device))
+        self._ag_events = []
+        for lo, hi in sorted(self.last_buckets):
+            s = (hi - lo) // w
+            out, inp = self.params[lo:hi], self.params[lo + r * s: lo + (r + 1) * s]
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    dist.all_gather_into_tensor(out, inp, group=self.group)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                engine.add_param_wait(lo, hi - lo, ev)
+                self._ag_events.append(ev)
+            else:
+                dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
 def all_reduce_scalar(value: float, device=None, group=None, dtype=torch.float64) -> float:
     rank, world = world_info()
     if world == 1:

@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from .callbacks import TrainerCallback, TrainerControl, TrainerState
-from .dp import GradBucketReducer, all_reduce_scalar, host_group, seeded_batches, shard_batches, world_info
+from .dp import GradBucketReducer, ShardedGradReducer, all_reduce_scalar, host_group, seeded_batches, shard_batches, world_info
 from .training_args import SLAMTrainingArguments, lr_lambda
 
 logger = logging.getLogger(__name__)
@@ -59,7 +59,17 @@ class SLAMTrainer:
         self.exp_avg_sq = torch.zeros(n, dtype=self.state_dtype, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         cd = getattr(self.args, "ddp_comm_dtype", None)
-        self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)
+        algo = getattr(self.args, "ddp_algo", "all_reduce") or "all_reduce"
+        if algo not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"ddp_algo must be all_reduce or rs_ag, got {algo!r}")
+        if algo == "rs_ag":
+            if getattr(self.args, "overlap_optimizer", False):
+                raise ValueError("ddp_algo=rs_ag runs the optimizer on shards; overlap_optimizer belongs to the replicated step")
+            chunk, n_chunks = model.engine.grad_chunk_info()
+            self.reducer = ShardedGradReducer(model.flat_grads, model.flat_params, chunk, comm_dtype=getattr(torch, cd) if cd else None)
+            self._chunk_sums = torch.zeros(n_chunks, dtype=torch.float32, device=dev)
+        else:
+            self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)
         self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
@@ -156,7 +166,10 @@ class SLAMTrainer:
         self._loss_n += 1
         self.reducer.finish()
         self.state.num_input_tokens_seen += int(glob_seen)
-        self._clip_and_update(lr, zero_grad=not a.overwrite_first_grad)
+        if getattr(self.reducer, "owned", None) is not None and (self.world > 1 or self.reducer.force):
+            self._clip_and_update_sharded(lr, zero_grad=not a.overwrite_first_grad)
+        else:
+            self._clip_and_update(lr, zero_grad=not a.overwrite_first_grad)
         self.state.global_step += 1
 
     def _clip_and_update(self, lr: float, zero_grad: bool):
@@ -170,6 +183,47 @@ class SLAMTrainer:
         else:
             eng.adamw_step(self.model.flat_master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1,
                            a.adam_beta2, a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=zero_grad)
+
+    def _clip_and_update_sharded(self, lr: float, zero_grad: bool):
+        """ddp_algo = rs_ag: after the reduce-scatters every rank holds the summed gradient of its own shard of each bucket
+        (and of the small replicated tail). Global norm = chunk sums of the own shards, summed over the ranks (disjoint
+        support: exact, and bit-identical to slam_grad_norm on the replicated buffer); AdamW on the owned ranges; bf16
+        parameters all-gathered on the communication stream while the next forward starts."""
+        a, eng, red = self.args, self.model.engine, self.reducer
+        cs = self._chunk_sums
+        cs.zero_()
+        tail_off, tail_cnt = red.tail
+        for off, cnt in red.owned:
+            eng.grad_sumsq_chunks(off, cnt, cs)
+        if tail_cnt and self.rank == 0:
+            eng.grad_sumsq_chunks(tail_off, tail_cnt, cs)
+        if self.world > 1 or red.force:
+            dist.all_reduce(cs, op=dist.ReduceOp.SUM, group=red.group)
+        eng.grad_norm_from_chunks(cs, a.max_grad_norm if a.max_grad_norm else 0.0, self.norm_out)
+        self.opt_step += 1
+        master = None if self.state_dtype == torch.bfloat16 else self.model.flat_master
+        for off, cnt in list(red.owned) + ([(tail_off, tail_cnt)] if tail_cnt else []):
+            eng.adamw_range(off, cnt, master, self.exp_avg, self.exp_avg_sq, self.norm_out, lr, a.adam_beta1, a.adam_beta2,
+                            a.adam_epsilon, a.weight_decay, self.opt_step, zero_grad=False)
+        if zero_grad:  # accumulate-mode backward: the regions this rank does not own hold partial sums, clear everything
+            eng.zero_grads()
+        red.gather_params(eng)
+        self._shards_stale = True  # master / moments of the other ranks' shards are out of date until gathered (checkpoints)
+
+    def _gather_optimizer_state(self):
+        """Before a checkpoint under ddp_algo = rs_ag: bring the full-size master / moment buffers up to date from the
+        owners of each shard (the file layout stays the replicated one, so a run may resume on any world size)."""
+        red = self.reducer
+        if not getattr(self, "_shards_stale", False) or not isinstance(red, ShardedGradReducer) or self.world == 1:
+            return
+        self.model.engine.join()
+        w, r = self.world, self.rank
+        bufs = [self.exp_avg, self.exp_avg_sq] + ([self.model.flat_master] if self.state_dtype == torch.float32 else [])
+        for lo, hi in red.last_buckets:
+            s = (hi - lo) // w
+            for b in bufs:
+                dist.all_gather_into_tensor(b[lo:hi], b[lo + r * s: lo + (r + 1) * s].clone(), group=red.group)
+        self._shards_stale = False
 
     def _sync_control(self):
         """Callbacks decide from rank-local clocks (RunTimeStopperCallback: `start_time` differs per rank), and
@@ -197,6 +251,7 @@ class SLAMTrainer:
         dt = time.time() - t0
         rec = {"step": self.state.global_step, "loss": loss, "grad_norm": float(self.norm_out[0]), "learning_rate": lr,
                "exposed_comm_ms": self.reducer.exposed_ms(),
+               "exposed_param_gather_ms": (self.model.engine.param_wait_ms() if hasattr(self.model.engine, "param_wait_ms") else 0.0),
                "num_input_tokens_seen": self.state.num_input_tokens_seen,
                "tokens_per_sec": (self.state.num_input_tokens_seen - tokens0) / max(dt, 1e-9)}
         self.state.log_history.append(rec)
@@ -296,6 +351,7 @@ class SLAMTrainer:
 
     def save_checkpoint(self):
         """HF-layout weights (UnitLM.save_pretrained) + optimizer/trainer state; keeps save_total_limit."""
+        self._gather_optimizer_state()
         if self.rank == 0:
             path = self._ckpt_dir(self.state.global_step)
             self.model.save_pretrained(path)

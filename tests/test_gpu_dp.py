@@ -33,7 +33,8 @@ base = dict(num_hidden_layers=4, hidden_size=cfg.hidden, num_attention_heads=cfg
 m = UnitLM(UnitLMConfig(base_model_name="local", base_config=base, vocab_size=cfg.vocab, max_tokens=512), seed=1)
 args = SLAMTrainingArguments(per_device_train_batch_size=2, gradient_accumulation_steps=2, learning_rate=1e-3,
                              max_grad_norm=0.5, logging_steps=0, ddp_bucket_layers=1,
-                             ddp_comm_dtype=os.environ.get("COMM") or None)
+                             ddp_comm_dtype=os.environ.get("COMM") or None, ddp_algo=os.environ.get("ALGO") or "all_reduce",
+                             optim_state_dtype=os.environ.get("OSD") or "float32")
 tr = SLAMTrainer(model=m, args=args)
 assert tr.reducer.force == force
 ranges = []
@@ -54,7 +55,9 @@ for step in range(3):
         micro.append({"input_ids": ids, "labels": lab})
     tr.optimizer_step(micro, 1e-3)
 torch.cuda.synchronize()
-torch.save({"master": m.flat_master.cpu(), "params": m.flat_params.cpu(), "ranges": ranges, "n": m.engine.n_params,
+torch.save({"master": (m.flat_master if m.flat_master is not None else m.flat_params).cpu(), "params": m.flat_params.cpu(),
+            "params_t": m.flat_params_t.cpu() if m.flat_params_t is not None else None, "gather_ms": m.engine.param_wait_ms(),
+            "owned": list(getattr(tr.reducer, "owned", []) or []), "ranges": ranges, "n": m.engine.n_params,
             "seen": tr.state.num_input_tokens_seen, "exposed_ms": tr.reducer.exposed_ms(),
             "world": dist.get_world_size() if force else 0}, os.environ["OUT"])
 if force:
@@ -70,11 +73,11 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, name, force, comm=""):
+def _run(tmp_path, name, force, comm="", algo="", osd=""):
     import torch
     out = str(tmp_path / f"{name}.pt")
     env = dict(os.environ, SLAM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), OUT=out,
-               SLAM_DP_FORCE="1" if force else "0", COMM=comm, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               SLAM_DP_FORCE="1" if force else "0", COMM=comm, ALGO=algo, OSD=osd, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -102,3 +105,23 @@ def test_dp_forced_single_rank_rccl_is_bit_identical(tmp_path):
     d = (bf["master"] - plain["master"]).abs().max().item()
     print(f"[parity] bf16 gradient exchange vs fp32 after 3 steps: max |dparam| = {d:.2e}")
     assert 0 < d < 5e-3
+
+
+@pytest.mark.parametrize("osd", ["float32", "bfloat16"])
+def test_rs_ag_forced_single_rank_rccl_is_bit_identical(tmp_path, osd):
+    """ddp_algo = rs_ag through RCCL on one rank (reduce_scatter_tensor / all_gather_into_tensor in place, the chunked
+    gradient norm summed by an all-reduce, AdamW per owned range, parameter all-gather on the communication stream with
+    the engine waiting per layer in the next forward, transposed weight images refreshed at the next backward): with one
+    rank every collective is the identity, so parameters, master weights and transposed images must equal the plain step
+    BIT FOR BIT - in both optimizer-state precisions."""
+    import torch
+    plain = _run(tmp_path, "plain", False, osd=osd)
+    rs = _run(tmp_path, "rs", True, algo="rs_ag", osd=osd)
+    ar = _run(tmp_path, "ar", True, algo="all_reduce", osd=osd)
+    for other, name in ((rs, "rs_ag"), (ar, "all_reduce")):
+        assert other["world"] == 1 and plain["seen"] == other["seen"] > 0
+        assert torch.equal(plain["master"], other["master"]), name
+        assert torch.equal(plain["params"], other["params"]), name
+    n = rs["n"]
+    assert rs["owned"] and sum(c for _, c in rs["owned"]) == (n // 8192) * 8192  # world 1: the shards are the whole buckets
+    assert rs["gather_ms"] >= 0.0
