@@ -116,6 +116,62 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "algorithmic_bytes": 271.2e6}
 
 
+def kernel_rooflines(model, iters=30, warm=10):
+    """The step's launch families by time (profiles/r3_step_kernel_stats.md), each timed live here as a STANDALONE launch
+    at the bench shape with HIP events on its launch stream: algorithmic flops / mean launch time against the dense bf16
+    MFMA peak. (Inside the step the weight-gradient GEMMs run as background launches beside the dgrad chain and every
+    launch takes longer than alone; the in-step durations are in the rocprof summary.)"""
+    from slamkit_amd import engine as E
+    lib = E.load_library()
+    st = E.current_stream_ptr()
+    dev = model.device
+    M, H, I, QKV = B * T, 896, 4864, 1152
+    bf = lambda *s, sc=0.5: (torch.randn(*s, device=dev) * sc).to(torch.bfloat16)  # noqa: E731
+    rows = []
+
+    def add(name, flops, fn):
+        us = _time_us(fn, iters=iters, warm=warm)
+        rows.append({"kernel": name, "gflop": round(flops / 1e9, 1), "us": round(us, 1), "tflops": round(flops / us / 1e6, 1),
+                     "frac": round(flops / (us * 1e-6) / PEAK_BF16, 4)})
+
+    x, x2 = bf(M, H), bf(M, I)
+    wgu, wd, wdt, wgut = bf(2 * I, H, sc=0.02), bf(H, I, sc=0.02), bf(I, H, sc=0.02), bf(H, 2 * I, sc=0.02)
+    gu, act, y = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=dev), torch.empty(M, I, dtype=torch.bfloat16, device=dev), bf(M, H)
+    dgu = bf(M, 2 * I, sc=0.1)
+    dw_gu = torch.empty(2 * I, H, dtype=torch.float32, device=dev)
+    dw_d = torch.empty(H, I, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(lib.slam_op_gemm_tn_workspace(M, 2 * I, H), lib.slam_op_gemm_tn_workspace(M, H, I)) // 4 + 16,
+                     dtype=torch.float32, device=dev)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    add("gate|up fwd + SwiGLU (NT 256x256 8-phase, persistent) M8192 N9728 K896", 2.0 * M * 2 * I * H,
+        lambda: lib.slam_op_gemm_nt_swiglu(p(x), p(wgu), p(gu), p(act), M, 2 * I, H, st))
+    add("gate|up wgrad (TN, contraction 8192 tokens) N9728 K896", 2.0 * M * 2 * I * H,
+        lambda: lib.slam_op_gemm_tn(p(dgu), p(x), p(dw_gu), 0, M, 2 * I, H, p(ws), st))
+    add("gate|up dgrad (NT) M8192 N896 K9728", 2.0 * M * 2 * I * H,
+        lambda: lib.slam_op_gemm_nt(p(dgu), p(wgut), p(y), None, None, M, H, 2 * I, 1, st))
+    add("down fwd + residual (NT) M8192 N896 K4864", 2.0 * M * I * H,
+        lambda: lib.slam_op_gemm_nt(p(x2), p(wd), p(y), None, p(x), M, H, I, 1, st))
+    add("down dgrad + fused SwiGLU backward (NT 256x256) M8192 N4864 K896", 2.0 * M * I * H,
+        lambda: lib.slam_op_gemm_nt_dswiglu(p(y), p(wdt), p(gu), M, I, H, st))
+    add("down wgrad (TN) N896 K4864", 2.0 * M * I * H,
+        lambda: lib.slam_op_gemm_tn(p(y), p(x2), p(dw_d), 0, M, H, I, p(ws), st))
+    # attention at the bench shape: 8 sequences x 1024 tokens, 14 / 2 heads of 64; causal-exact flops
+    nH, nKV, hd = 14, 2, 64
+    qkv = bf(M, (nH + 2 * nKV) * hd, sc=1.0)
+    o = torch.empty(M, nH * hd, dtype=torch.bfloat16, device=dev)
+    do, dqkv = bf(M, nH * hd, sc=1.0), torch.empty(M, (nH + 2 * nKV) * hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(nH * M, dtype=torch.float32, device=dev)
+    ss = (torch.arange(M, device=dev, dtype=torch.int32) // T) * T
+    se = ss + T
+    aws = torch.empty(lib.slam_op_attn_bwd_workspace(M, nH, hd) // 4 + 16, dtype=torch.float32, device=dev)
+    fl = 4.0 * hd * (T * (T + 1) / 2) * B * nH
+    add("attention fwd (+ block-order plan) 8x1024, 14/2 heads of 64", fl,
+        lambda: lib.slam_op_attn_fwd(p(qkv), p(o), p(lse), p(ss), M, nH, nKV, hd, st))
+    add("attention bwd (plan + dQ + dK/dV + reduce; 7 matmuls, counted as 5)", 2.5 * fl,
+        lambda: lib.slam_op_attn_bwd(p(qkv), p(o), p(do), p(lse), p(dqkv), p(aws), p(ss), p(se), M, nH, nKV, hd, st))
+    return rows
+
+
 PEAK_HBM = 8.0e12  # B/s, MI355X_MICROARCH.md (about 6.3e12 reachable by a streaming copy)
 
 
@@ -165,7 +221,8 @@ def hbm_kernel_rates(model, trainer):
         us = _time_us(lambda: eng.adamw_step(model.flat_master, trainer.exp_avg, trainer.exp_avg_sq, trainer.norm_out, 0.0, 0.9, 0.999,
                                              1e-8, 0.0, 1000, zero_grad=False), iters=5, warm=2)
         # (the launch includes the transposed-weight-image refresh: + 4 B per matrix element)
-        row("adamw_kernel + transpose_bf16_kernel (fp32 master + moments)", us, 34 * n, "30 B/param AdamW + 4 B/param image refresh")
+        row("adamw_tile_kernel (fp32 master + moments; writes the transposed bf16 images itself)", us, 32 * n,
+            "30 B/param AdamW + 2 B/param transposed image")
     us = _time_us(lambda: eng.grad_norm(0.5, trainer.norm_out), iters=10, warm=2)
     row("sumsq_partial_kernel + norm_finish_kernel (global gradient norm)", us, 4 * n, "4 B/param")
     return out
@@ -461,6 +518,7 @@ def main():
                                  overlap_optimizer=os.environ.get("SLAM_OVERLAP_OPTIMIZER", "0") == "1",
                                  overwrite_first_grad=os.environ.get("SLAM_OVERWRITE_FIRST_GRAD", "1") == "1",
                                  ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"),
+                                 ddp_algo=os.environ.get("SLAM_DDP_ALGO", "all_reduce"),
                                  optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "float32"))
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
@@ -520,11 +578,14 @@ def main():
                        "final_loss": round(loss, 4),
                        "ms_per_step_median": round(ms_median, 3), "ms_per_step_min": round(per_step[0], 3),
                        "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
-                       "exposed_comm_ms_last_step": round(exposed, 3)},
+                       "ddp_algo": args.ddp_algo if world > 1 else None,
+                       "exposed_comm_ms_last_step": round(exposed, 3),
+                       "exposed_param_gather_ms_total": round(model.engine.param_wait_ms(), 3)},
         }
         roof = dominant_kernel_roofline(model)
         roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
+        roof["kernels"] = kernel_rooflines(model)
         out["roofline"] = roof
         out["hbm_kernels"] = hbm
         if extras is not None:

@@ -135,6 +135,12 @@ int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp
 int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out, double lr,
                          double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t zero_grad,
                          slam_stream_t stream);
+/* The middle precision: fp32 master weights, Adam moments STORED in bf16 (fp32 arithmetic per element, one rounding on the
+ * way back): 22 B/param instead of 30. With transposed weight images bound, all three forms write those images from the
+ * optimizer kernel itself (64 x 64 tiles through LDS) - there is no separate transpose pass after the update. */
+int slam_adamw_step_bf16_moments(SlamEngine* h, float* master_f32, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                                 const float* norm_out, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 int32_t step, int32_t zero_grad, slam_stream_t stream);
 /* ---- sharded optimizer step: the data-parallel "rs_ag" exchange (replaces torch DDP's all-reduce of
  * every gradient followed by N identical optimizer steps, /root/reference config/training_args/default.yaml:18 +
  * site-packages transformers/trainer.py) -------------------------------------------------------------------------------
@@ -154,6 +160,9 @@ int slam_grad_norm_from_chunks(SlamEngine* h, const float* chunk_sums, float max
 int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master_f32, float* exp_avg, float* exp_avg_sq,
                      const float* norm_out, double lr, double beta1, double beta2, double eps, double weight_decay,
                      int32_t step, int32_t zero_grad, slam_stream_t stream);
+int slam_adamw_range_bf16_moments(SlamEngine* h, int64_t offset, int64_t count, float* master_f32, void* exp_avg_bf16,
+                                  void* exp_avg_sq_bf16, const float* norm_out, double lr, double beta1, double beta2, double eps,
+                                  double weight_decay, int32_t step, int32_t zero_grad, slam_stream_t stream);
 int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* exp_avg_bf16, void* exp_avg_sq_bf16,
                           const float* norm_out, double lr, double beta1, double beta2, double eps, double weight_decay,
                           int32_t step, int32_t zero_grad, slam_stream_t stream);

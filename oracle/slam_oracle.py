@@ -381,6 +381,25 @@ def adamw_update(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def adamw_update_bf16_moments(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    """The middle optimizer precision of the engine (slam_adamw_step_bf16_moments; no counterpart in the reference: its
+    recipe keeps everything in bf16, torch's default everything in fp32): fp32 master `p`, Adam moments STORED in bf16 -
+    widened to fp32, updated with adamw_update's own expressions, rounded once when stored; the parameter step uses
+    the unrounded fp32 moments of this step."""
+    assert p.dtype == torch.float32 and m.dtype == v.dtype == torch.bfloat16
+    f = torch.float32
+    mf, vf, gf = m.to(f), v.to(f), g.to(f)
+    p.mul_(1 - lr * wd)
+    mf = mf * b1 + gf * (1 - b1)
+    vf = vf * b2 + gf * gf * (1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    den = vf.sqrt() / math.sqrt(bc2) + eps
+    p.addcdiv_(mf, den, value=-(lr / bc1))
+    m.copy_(mf.to(torch.bfloat16))
+    v.copy_(vf.to(torch.bfloat16))
+
+
 def adamw_update_bf16(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     """torch.optim.AdamW(fused=True) on bf16 parameters with bf16 moments, in place - the optimizer precision of the
     Slam recipe (/root/reference config/model/slam.yaml:9 `torch_dtype: bfloat16`; the HF Trainer builds AdamW on the

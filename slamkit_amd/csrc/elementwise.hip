@@ -691,6 +691,33 @@ __global__ void norm_finish_kernel(const float* __restrict__ part, int nb, float
   }
 }
 
+struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; int zero_grad; };
+template <typename MT> SLAM_DEVICE void load4(const MT* q, float* f);
+template <> SLAM_DEVICE void load4<float>(const float* q, float* f) {
+  const float4 t = *reinterpret_cast<const float4*>(q);
+  f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+}
+template <> SLAM_DEVICE void load4<bf16_t>(const bf16_t* q, float* f) {
+  const uint2 t = *reinterpret_cast<const uint2*>(q);
+  f[0] = __uint_as_float(t.x << 16); f[1] = __uint_as_float(t.x & 0xffff0000u);
+  f[2] = __uint_as_float(t.y << 16); f[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+SLAM_DEVICE void store4(float* q, const float* f) { *reinterpret_cast<float4*>(q) = make_float4(f[0], f[1], f[2], f[3]); }
+SLAM_DEVICE void store4(bf16_t* q, const float* f) {
+  uint2 o;
+  o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+  *reinterpret_cast<uint2*>(q) = o;
+}
+// one element of torch.optim.AdamW (fp32 master: adamw_kernel's expression; bf16 state: the fused-kernel form with lerp)
+template <bool MASTER>
+SLAM_DEVICE void adam_elem(float& p, float& m, float& v, float g, const AdamHyper& h) {
+  p *= (1.f - h.lr * h.wd);
+  if (MASTER) m = h.b1 * m + (1.f - h.b1) * g;
+  else m = m + (1.f - h.b1) * (g - m);
+  v = h.b2 * v + (1.f - h.b2) * g * g;
+  const float den = sqrtf(v) / h.bc2_sqrt + h.eps;
+  p -= (h.lr / h.bc1) * (m / den);
+}
 // torch.optim.AdamW semantics on fp32 master weights; writes the bf16 working copy; optional
 // grad zeroing. Traffic: 30 B/param (fp32 g,p,m,v read; p,m,v + bf16 written), 34 with zeroing.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_t* __restrict__ pb,
@@ -708,15 +735,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_
   float4 vv = *reinterpret_cast<float4*>(v + i);
   float ga[4] = {gv.x * cs, gv.y * cs, gv.z * cs, gv.w * cs};
   float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
-  const float step = lr / bc1;
+  const AdamHyper h = {lr, b1, b2, eps, wd, bc1, bc2_sqrt, zero_grad};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    pa[j] *= (1.f - lr * wd);
-    ma[j] = b1 * ma[j] + (1.f - b1) * ga[j];
-    va[j] = b2 * va[j] + (1.f - b2) * ga[j] * ga[j];
-    float den = sqrtf(va[j]) / bc2_sqrt + eps;
-    pa[j] -= step * (ma[j] / den);
-  }
+  for (int j = 0; j < 4; ++j) adam_elem<true>(pa[j], ma[j], va[j], ga[j], h);  // the tile kernel's expression: bit-identical updates
   *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
   *reinterpret_cast<float4*>(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *reinterpret_cast<float4*>(v + i) = make_float4(va[0], va[1], va[2], va[3]);
@@ -744,15 +765,9 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p,
   unpack_bf16x8(*reinterpret_cast<const uint4*>(p + i), pa);
   unpack_bf16x8(*reinterpret_cast<const uint4*>(m + i), ma);
   unpack_bf16x8(*reinterpret_cast<const uint4*>(v + i), va);
-  const float step = lr / bc1;
+  const AdamHyper h = {lr, b1, b2, eps, wd, bc1, bc2_sqrt, zero_grad};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    pa[j] *= (1.f - lr * wd);
-    ma[j] = ma[j] + (1.f - b1) * (ga[j] - ma[j]);
-    va[j] = b2 * va[j] + (1.f - b2) * ga[j] * ga[j];
-    const float den = sqrtf(va[j]) / bc2_sqrt + eps;
-    pa[j] -= step * (ma[j] / den);
-  }
+  for (int j = 0; j < 8; ++j) adam_elem<false>(pa[j], ma[j], va[j], ga[j], h);
   *reinterpret_cast<uint4*>(p + i) = pack_bf16x8(pa);
   *reinterpret_cast<uint4*>(m + i) = pack_bf16x8(ma);
   *reinterpret_cast<uint4*>(v + i) = pack_bf16x8(va);
@@ -760,6 +775,73 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p,
     *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
     *reinterpret_cast<float4*>(g + i + 4) = make_float4(0, 0, 0, 0);
   }
+}
+
+// ---- AdamW that also writes the TRANSPOSED bf16 weight image (round 3: replaces the separate transpose_bf16 pass after
+// the optimizer: 4 B per matrix element of extra traffic and a kernel that ran at 2.4 TB/s). One block = one 64 x 64 tile
+// of a [R][C] weight matrix (grid.z = same-shaped matrices at a constant stride: one per layer): every row segment of the
+// tile is one contiguous 256 B (fp32) / 128 B (bf16) piece of each state array; the updated bf16 tile goes out row-major
+// (pb) and, through a padded LDS tile, column-major (pt[C][R]). Per-element arithmetic is the flat kernels' own.
+// MT = float / bf16_t: storage type of the Adam moments; MASTER: fp32 master weights (else the bf16 parameters ARE the state).
+template <typename MT, bool MASTER>
+__global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, bf16_t* __restrict__ pt,
+                                                         float* __restrict__ g, MT* __restrict__ m, MT* __restrict__ v, int R, int C,
+                                                         size_t batch_stride, const float* __restrict__ clip, AdamHyper h) {
+  __shared__ uint16_t T[64][66];  // transposed bf16 tile: T[col][row], rows padded to 132 B
+  const size_t boff = (size_t)blockIdx.z * batch_stride;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, rr = tid >> 4, cc = (tid & 15) * 4;
+  const float cs = clip ? clip[1] : 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rr + 16 * i;
+    const size_t idx = boff + (size_t)(r0 + row) * C + c0 + cc;
+    float ga[4], pa[4], ma[4], va[4];
+    load4<float>(g + idx, ga);
+    if (MASTER) load4<float>(p + idx, pa);
+    else load4<bf16_t>(pb + idx, pa);
+    load4<MT>(m + idx, ma);
+    load4<MT>(v + idx, va);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adam_elem<MASTER>(pa[j], ma[j], va[j], ga[j] * cs, h);
+    if (MASTER) store4(p + idx, pa);
+    store4(m + idx, ma);
+    store4(v + idx, va);
+    store4(pb + idx, pa);
+    if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) T[cc + j][row] = (uint16_t)(pack_bf16x2(pa[j], 0.f) & 0xffffu);
+  }
+  __syncthreads();
+  const int orow = tid >> 2, seg = (tid & 3) * 16;  // transposed row c0 + orow, its 16 elements r0 + seg ..
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&T[orow][seg]);
+  uint4 a = make_uint4(src[0], src[1], src[2], src[3]), b = make_uint4(src[4], src[5], src[6], src[7]);
+  bf16_t* dst = pt + boff + (size_t)(c0 + orow) * R + r0 + seg;
+  *reinterpret_cast<uint4*>(dst) = a;
+  *reinterpret_cast<uint4*>(dst + 8) = b;
+}
+// the vectors between the matrices (norm weights, biases): count elements at a constant stride, grid.y = instances
+template <typename MT, bool MASTER>
+__global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, float* __restrict__ g,
+                                                            MT* __restrict__ m, MT* __restrict__ v, size_t n, size_t stride,
+                                                            const float* __restrict__ clip, AdamHyper h) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const size_t idx = (size_t)blockIdx.y * stride + i;
+  const float cs = clip ? clip[1] : 1.f;
+  float ga[4], pa[4], ma[4], va[4];
+  load4<float>(g + idx, ga);
+  if (MASTER) load4<float>(p + idx, pa);
+  else load4<bf16_t>(pb + idx, pa);
+  load4<MT>(m + idx, ma);
+  load4<MT>(v + idx, va);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) adam_elem<MASTER>(pa[j], ma[j], va[j], ga[j] * cs, h);
+  if (MASTER) store4(p + idx, pa);
+  store4(m + idx, ma);
+  store4(v + idx, va);
+  store4(pb + idx, pa);
+  if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
@@ -969,6 +1051,37 @@ int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float*
   float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
   adamw_bf16_kernel<<<nblocks(n / 8, 256), 256, 0, st>>>(p, g, m, v, n, clip, (float)lr, (float)b1, (float)b2, (float)eps,
                                                          (float)wd, bc1, bc2s, zero_grad);
+  LAUNCH_RET();
+}
+static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int step, int zero_grad) {
+  // bias corrections in double like torch.optim.AdamW (python floats), then fp32 in the kernel
+  AdamHyper h;
+  h.lr = (float)lr; h.b1 = (float)b1; h.b2 = (float)b2; h.eps = (float)eps; h.wd = (float)wd;
+  h.bc1 = (float)(1.0 - pow(b1, (double)step));
+  h.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
+  h.zero_grad = zero_grad;
+  return h;
+}
+// mode 0: fp32 master + fp32 moments; 1: fp32 master + bf16 moments; 2: bf16 parameters + bf16 moments (no master)
+int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, void* v, int R, int C, int batch, size_t batch_stride,
+                const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
+  if ((R & 63) || (C & 63) || batch < 1 || mode < 0 || mode > 2) return -1;
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, step, zero_grad);
+  const dim3 grid(C / 64, R / 64, batch);
+  if (mode == 0) adamw_tile_kernel<float, true><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
+  else if (mode == 1) adamw_tile_kernel<bf16_t, true><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  else adamw_tile_kernel<bf16_t, false><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  LAUNCH_RET();
+}
+int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, size_t n, int batch, size_t stride, const float* clip,
+                  double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
+  if ((n & 3) || batch < 1 || mode < 0 || mode > 2) return -1;
+  if (n == 0) return 0;
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, step, zero_grad);
+  const dim3 grid(nblocks(n / 4, 256), batch);
+  if (mode == 0) adamw_strided_kernel<float, true><<<grid, 256, 0, st>>>(p, pb, g, (float*)m, (float*)v, n, stride, clip, h);
+  else if (mode == 1) adamw_strided_kernel<bf16_t, true><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
+  else adamw_strided_kernel<bf16_t, false><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
   LAUNCH_RET();
 }
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st) {

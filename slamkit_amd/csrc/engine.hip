@@ -108,12 +108,14 @@ struct SlamEngine {
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
+  size_t gemm_ws_bytes = 0;
   int *seg_s, *seg_e, *attn_plan_buf;
 
   // last forward
   int B = 0, T = 0;
   bool have_fwd = false, have_loss = false;
   bool fuse_swiglu = false, fuse_dswiglu = true;
+  bool fuse_adamw_t = true;  // "fuse_adamw_t": AdamW writes the transposed weight images itself (0: separate transpose pass)
   const int64_t* last_ids = nullptr;
   const int* cur_seg_s = nullptr;
   const int* cur_seg_e = nullptr;
@@ -193,7 +195,8 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->seg_s = c.take<int>(M);
   e->seg_e = c.take<int>(M);
   e->attn_plan_buf = c.take<int>(attn_plan_ints((int)M));
-  e->gemm_ws = c.take<float>(max_gemm_ws(e, (int)M) / sizeof(float));
+  e->gemm_ws_bytes = max_gemm_ws(e, (int)M);
+  e->gemm_ws = c.take<float>(e->gemm_ws_bytes / sizeof(float));
   size_t part = (size_t)rmsnorm_bwd_blocks((int)M) * H;
   size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
   if (part2 > part) part = part2;
@@ -309,6 +312,44 @@ int wait_params(SlamEngine* h, int64_t lo, int64_t hi, hipStream_t st) {
   return 0;
 }
 int join_params(SlamEngine* h, hipStream_t st) { return h->pwaits.empty() ? 0 : wait_params(h, 0, h->n_params, st); }
+
+// AdamW over the parameters [chunk c of the model]: c = 0 embedding, 1 + l = decoder layer l, L + 1 = final norm; c < 0 = all.
+// With transposed weight images bound, every matrix goes through the tile kernel that writes its transposed image in the
+// same pass (no separate transpose launch), the vectors between them through the strided kernel.
+// mode 0: fp32 master + fp32 moments, 1: fp32 master + bf16 moments, 2: bf16 parameters + bf16 moments.
+int adamw_model(SlamEngine* h, int mode, float* master, void* m, void* v, const float* norm_out, double lr, double b1, double b2,
+                double eps, double wd, int step, int zero_grad, int chunk, hipStream_t st) {
+  const SlamModelDesc& d = h->d;
+  const int L = d.n_layers, H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
+  bf16_t* P = h->params;
+  bf16_t* Pt = h->params_t;
+  float* G = h->grads;
+  const size_t esz = mode == 0 ? 4 : 2;
+  auto mat = [&](int64_t off, int R, int C, int batch) -> int {
+    return adamw_tiles(mode, master ? master + off : nullptr, P + off, Pt + off, G + off, (char*)m + off * esz, (char*)v + off * esz, R, C,
+                       batch, (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
+  };
+  auto vec = [&](int64_t off, size_t n, int batch) -> int {
+    return adamw_strided(mode, master ? master + off : nullptr, P + off, G + off, (char*)m + off * esz, (char*)v + off * esz, n, batch,
+                         (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
+  };
+  int r = 0;
+  if (chunk < 0 || chunk == 0) r = mat(h->off_embed, h->vpad, H, 1);
+  if (r) return r;
+  const int l0 = chunk < 0 ? 0 : chunk - 1, nl = chunk < 0 ? L : 1;
+  if (chunk < 0 || (chunk >= 1 && chunk <= L)) {
+    const LayerOff& o = h->lo[l0];
+    if ((r = vec(o.ln1, (size_t)H, nl))) return r;
+    if ((r = mat(o.wqkv, h->QKV, H, nl))) return r;
+    if ((r = vec(o.bqkv, (size_t)h->QKV, nl))) return r;
+    if ((r = mat(o.wo, H, HD, nl))) return r;
+    if ((r = vec(o.ln2, (size_t)H, nl))) return r;
+    if ((r = mat(o.wgu, 2 * I, H, nl))) return r;
+    if ((r = mat(o.wd, H, I, nl))) return r;
+  }
+  if (chunk < 0 || chunk == L + 1) r = vec(h->off_norm, (size_t)H, 1);
+  return r;
+}
 
 }  // namespace
 
@@ -451,6 +492,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "fuse_adamw_t") && h) { h->fuse_adamw_t = value != 0; return SLAM_OK; }
   return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
 }
 
@@ -577,7 +619,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   auto wait_side = [&](int layer, int k) -> int { return two ? (int)hipStreamWaitEvent(st, ev(layer, k), 0) : 0; };
 
   CK(fork(L, 0));
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, ws, two ? 1 : 0));
+  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
   bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
@@ -591,7 +633,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     LayerAct& a = h->la[l];
     // MLP
     CK(fork(l, 0));
-    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, ws, two ? 1 : 0));
+    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
     CK(mark(l, 4));  // dh has been read by the wgrad
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
@@ -600,13 +642,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
     CK(fork(l, 1));
-    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, ws, two ? 1 : 0));
+    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     if (l + 1 < L) CK(wait_side(l + 1, 5));  // the previous layer's wo wgrad still reads dh2
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
     CK(fork(l, 2));
-    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, ws, two ? 1 : 0));
+    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
     CK(mark(l, 5));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
@@ -614,7 +656,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
     CK(fork(l, 3));
-    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, ws, two ? 1 : 0));
+    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
     CK(mark(l, 6));
     CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
     CK(wait_side(l, 4));  // this layer's wd wgrad still reads dh
@@ -647,7 +689,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   CK(fork(L, 1));
   if (VP == VPAD_SMALL) {
     CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
-    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, ws, two ? 1 : 0));
+    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
   } else {
     CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
   }
@@ -690,17 +732,27 @@ int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t
   return SLAM_OK;
 }
 
-int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const float* norm_out, double lr, double b1,
-                    double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
-  if (!h || !master || !m || !v || step < 1) return SLAM_EINVAL;
+static int adamw_any(SlamEngine* h, int mode, float* master, void* m, void* v, const float* norm_out, double lr, double b1, double b2,
+                     double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
+  if (!h || !m || !v || step < 1 || (mode != 2 && !master)) return SLAM_EINVAL;
   if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  if (h->n_params & 7) return h->fail(SLAM_EINVAL, "parameter count must be a multiple of 8");
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   CK(join_params(h, st));
-  if (!h->overlap_adamw) {
-    CK(adamw(master, h->params, h->grads, m, v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+  const bool fused = h->params_t != nullptr && h->fuse_adamw_t;
+  if (!h->overlap_adamw || mode != 0) {
+    if (fused) {
+      CK(adamw_model(h, mode, master, m, v, norm_out, lr, b1, b2, eps, wd, step, zero_grad, -1, st));
+      h->params_t_dirty = false;
+      return SLAM_OK;
+    }
+    if (mode == 0) CK(adamw(master, h->params, h->grads, (float*)m, (float*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    else if (mode == 2) CK(adamw_bf16(h->params, h->grads, (bf16_t*)m, (bf16_t*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    else CK(adamw_strided(1, master, h->params, h->grads, m, v, (size_t)h->n_params, 1, 0, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
     return slam_refresh_transposed(h, stream);
   }
+  // "overlap_adamw" (fp32 state): per-layer chunks on the engine's side stream; the next forward waits per layer
   CK(ensure_side(h));
   CK((int)hipEventRecord(h->ev_fork, st));
   CK((int)hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -708,20 +760,24 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
   const int L = d.n_layers, H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
   bf16_t* Pt = h->params_t;
   for (int c = 0; c < L + 2; ++c) {
-    const int64_t lo = c == 0 ? 0 : c <= L ? h->lo[c - 1].ln1 : h->off_norm;
-    const int64_t hi = c == 0 ? h->lo[0].ln1 : c < L ? h->lo[c].ln1 : c == L ? h->off_norm : h->n_params;
-    CK(adamw(master + lo, h->params + lo, h->grads + lo, m + lo, v + lo, (size_t)(hi - lo), norm_out, lr, b1, b2, eps, wd, step,
-             zero_grad, h->side));
-    if (Pt) {
-      const bf16_t* P = h->params;
-      if (c == 0) {
-        CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, h->vpad, H, 1, 0, h->side));
-      } else if (c <= L) {
-        const LayerOff& o = h->lo[c - 1];
-        CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, 1, 0, h->side));
-        CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, 1, 0, h->side));
-        CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, 1, 0, h->side));
-        CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, 1, 0, h->side));
+    if (fused) {
+      CK(adamw_model(h, 0, master, m, v, norm_out, lr, b1, b2, eps, wd, step, zero_grad, c, h->side));
+    } else {
+      const int64_t lo = c == 0 ? 0 : c <= L ? h->lo[c - 1].ln1 : h->off_norm;
+      const int64_t hi = c == 0 ? h->lo[0].ln1 : c < L ? h->lo[c].ln1 : c == L ? h->off_norm : h->n_params;
+      CK(adamw(master + lo, h->params + lo, h->grads + lo, (float*)m + lo, (float*)v + lo, (size_t)(hi - lo), norm_out, lr, b1, b2, eps, wd, step,
+               zero_grad, h->side));
+      if (Pt) {
+        const bf16_t* P = h->params;
+        if (c == 0) {
+          CK(transpose_bf16(P + h->off_embed, Pt + h->off_embed, h->vpad, H, 1, 0, h->side));
+        } else if (c <= L) {
+          const LayerOff& o = h->lo[c - 1];
+          CK(transpose_bf16(P + o.wqkv, Pt + o.wqkv, h->QKV, H, 1, 0, h->side));
+          CK(transpose_bf16(P + o.wo, Pt + o.wo, H, HD, 1, 0, h->side));
+          CK(transpose_bf16(P + o.wgu, Pt + o.wgu, 2 * I, H, 1, 0, h->side));
+          CK(transpose_bf16(P + o.wd, Pt + o.wd, H, I, 1, 0, h->side));
+        }
       }
     }
     CK((int)hipEventRecord(h->ev_chunk[c], h->side));
@@ -730,16 +786,20 @@ int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const floa
   return SLAM_OK;
 }
 
+int slam_adamw_step(SlamEngine* h, float* master, float* m, float* v, const float* norm_out, double lr, double b1,
+                    double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
+  return adamw_any(h, 0, master, m, v, norm_out, lr, b1, b2, eps, wd, step, zero_grad, stream);
+}
+
+int slam_adamw_step_bf16_moments(SlamEngine* h, float* master, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out,
+                                 double lr, double b1, double b2, double eps, double wd, int32_t step, int32_t zero_grad,
+                                 slam_stream_t stream) {
+  return adamw_any(h, 1, master, exp_avg_bf16, exp_avg_sq_bf16, norm_out, lr, b1, b2, eps, wd, step, zero_grad, stream);
+}
+
 int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf16, const float* norm_out, double lr,
                          double b1, double b2, double eps, double wd, int32_t step, int32_t zero_grad, slam_stream_t stream) {
-  if (!h || !exp_avg_bf16 || !exp_avg_sq_bf16 || step < 1) return SLAM_EINVAL;
-  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
-  if (h->n_params & 7) return h->fail(SLAM_EINVAL, "parameter count must be a multiple of 8");
-  hipStream_t st = (hipStream_t)stream;
-  CK(join_optimizer(h, st));
-  CK(adamw_bf16(h->params, h->grads, (bf16_t*)exp_avg_bf16, (bf16_t*)exp_avg_sq_bf16, (size_t)h->n_params, norm_out, lr, b1,
-                b2, eps, wd, step, zero_grad, st));
-  return slam_refresh_transposed(h, stream);
+  return adamw_any(h, 2, nullptr, exp_avg_bf16, exp_avg_sq_bf16, norm_out, lr, b1, b2, eps, wd, step, zero_grad, stream);
 }
 
 // ---- sharded optimizer (data-parallel "rs_ag": reduce-scatter gradients, update the owned 1/N shard, all-gather bf16
@@ -772,6 +832,21 @@ int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master
   CK(join_optimizer(h, st));
   if (count)
     CK(adamw(master, h->params + offset, h->grads + offset, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+  h->params_t_dirty = h->params_t != nullptr;
+  return SLAM_OK;
+}
+
+int slam_adamw_range_bf16_moments(SlamEngine* h, int64_t offset, int64_t count, float* master, void* m_bf16, void* v_bf16,
+                                  const float* norm_out, double lr, double b1, double b2, double eps, double wd, int32_t step,
+                                  int32_t zero_grad, slam_stream_t stream) {
+  if (!h || !master || !m_bf16 || !v_bf16 || step < 1 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3))
+    return SLAM_EINVAL;
+  if (!h->grads || !h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  hipStream_t st = (hipStream_t)stream;
+  CK(join_optimizer(h, st));
+  if (count)
+    CK(adamw_strided(1, master, h->params + offset, h->grads + offset, m_bf16, v_bf16, (size_t)count, 1, 0, norm_out, lr, b1, b2, eps, wd,
+                     step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
 }
@@ -851,7 +926,7 @@ int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, 
 size_t slam_op_gemm_tn_workspace(int M, int N, int K) { return gemm_tn_workspace_bytes(M, N, K); }
 int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,
                     slam_stream_t s) {
-  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, (hipStream_t)s);
+  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, gemm_tn_workspace_bytes(M, N, K), (hipStream_t)s);
 }
 int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s) {
   return rmsnorm_fwd((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, M, H, eps, (hipStream_t)s);

@@ -1727,15 +1727,17 @@ static Plan224 tn224_plan(int M, int N, int K, int orient, int max_split = -1) {
   best.tiles_b = orient == 1 ? K / 224 : N / 224;
   return best;
 }
-static size_t tn224_workspace_bytes(int M, int N, int K) {
-  // sized for every setting the options can take later (forced on, any split limit): any eligible shape reserves its slabs
-  const bool o1 = (M % BK == 0) && (N % 256 == 0) && (K % 224 == 0), o2 = (M % BK == 0) && (K % 256 == 0) && (N % 224 == 0);
+static size_t tn224_workspace_bytes(int Mmax, int N, int K) {
+  // sized for every plan that can run later: any contraction length up to Mmax (packed micro-batches vary) under every
+  // split limit the options can take (forced on, foreground or background): any eligible shape reserves its slabs
+  const bool o1 = (N % 256 == 0) && (K % 224 == 0), o2 = (K % 256 == 0) && (N % 224 == 0);
   if (!o1 && !o2) return 0;
   int slabs = 0;
-  for (int ms = 1; ms <= 16; ++ms) {
-    const Plan224 pl = tn224_plan(M, N, K, o1 ? 1 : 2, ms);
-    if (pl.slabs > slabs) slabs = pl.slabs;
-  }
+  for (int ks = 1; ks <= Mmax / BK; ++ks)
+    for (int ms = 1; ms <= 16; ++ms) {
+      const Plan224 pl = tn224_plan(ks * BK, N, K, o1 ? 1 : 2, ms);
+      if (pl.slabs > slabs) slabs = pl.slabs;
+    }
   return (size_t)slabs * 256 * 224 * sizeof(float);
 }
 static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
@@ -1768,24 +1770,36 @@ static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumu
   return (int)hipGetLastError();
 }
 
-size_t gemm_tn_workspace_bytes(int M, int N, int K) {
-  size_t split = (size_t)gemm_tn_splits(M, N, K) * N * K * sizeof(float);
-  if ((N % BM == 0) && (K % BN == 0) && (M % BK == 0)) {
-    BalPlan pl = tn_bal_plan(M, N, K);
-    size_t bal = ((pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0) + (size_t)pl.SB_act * pl.T_B * 128 * 128) * sizeof(float);
-    if (bal > split) split = bal;
-  }
-  const size_t t224 = tn224_workspace_bytes(M, N, K);
-  if (t224 > split) split = t224;
-  return split;
+static size_t bal_plan_bytes(const BalPlan& pl, int N, int K) {
+  return ((pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0) + (size_t)pl.SB_act * pl.T_B * 128 * 128) * sizeof(float);
+}
+// Workspace for dW[N,K] with contractions of up to Mmax rows: the maximum over EVERY plan gemm_tn can choose later - any
+// contraction length M <= Mmax (the planners re-plan from the runtime M, which varies per packed micro-batch) under any
+// split limit (foreground 8, the side stream's "gemm_tn_bal_bg_max_split") - not just the plan of M = Mmax (round 2 sized
+// for that one: with H = 256, I = 1024, Mmax = 2048 the plan at M = 1600 needed 10 MiB of an 8 MiB allocation). gemm_tn
+// also checks the chosen plan against the capacity it is given and fails instead of writing past it.
+size_t gemm_tn_workspace_bytes(int Mmax, int N, int K) {
+  size_t need = (size_t)gemm_tn_splits(Mmax, N, K) * N * K * sizeof(float);  // split-K fallback: grows with M
+  if ((N % BM == 0) && (K % BN == 0))
+    for (int ks = 1; ks <= Mmax / BK; ++ks)
+      for (int ms = 1; ms <= 8; ++ms) {
+        const size_t b = bal_plan_bytes(tn_bal_plan(ks * BK, N, K, ms), N, K);
+        if (b > need) need = b;
+      }
+  const size_t t224 = tn224_workspace_bytes(Mmax, N, K);
+  if (t224 > need) need = t224;
+  return need;
 }
 
 // dW[N,K] (fp32) (+)= dY[M,N]^T X[M,K]; contraction over M; split-K partials in `ws`.
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
-            int ldx, float* ws, hipStream_t st, int background) {
+            int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
-  if (const int orient = tn224_orient(M, N, K, background))
+  if (const int orient = tn224_orient(M, N, K, background)) {
+    const Plan224 pl = tn224_plan(M, N, K, orient, background ? g_tn224_bg_max_split : g_tn224_max_split);
+    if ((size_t)pl.slabs * 256 * 224 * sizeof(float) > ws_bytes) return -3;
     return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st);
+  }
   if (tn_bal_ok(M, N, K)) {
     static bool attr = false;
     if (!attr) {
@@ -1795,6 +1809,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
       attr = true;
     }
     const BalPlan pl = tn_bal_plan(M, N, K, background ? g_bal_bg_max_split : 8);
+    if (bal_plan_bytes(pl, N, K) > ws_bytes) return -3;
     BalArgs a{};
     a.A = dY; a.B = X; a.dW = dW; a.lda = ldy; a.ldb = ldx; a.ldc = K;
     a.tiles_r = N / BM; a.tiles_c = K / BN; a.KS = M / BK; a.group_rows = g_group_rows;
@@ -1813,6 +1828,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int splits = gemm_tn_splits(M, N, K);
   int per = (((M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (M + per - 1) / per;
+  if ((size_t)splits * N * K * sizeof(float) > ws_bytes) return -3;
   GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
   const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
   int e = dma_ok ? launch<true, true, true, true>(a, splits, st) : launch<true, true, true, false>(a, splits, st);

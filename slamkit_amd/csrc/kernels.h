@@ -41,8 +41,9 @@ int gemm_tn_splits(int M, int N, int K);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
 // background = 1: the launch shares the GPU with other streams (the engine's wgrad side stream): plans for CU-time per
 // flop instead of chip fill (no K-splitting on the 256 x 224 kernel)
+// ws_bytes: capacity of `ws` (from gemm_tn_workspace_bytes(Mmax, N, K) with Mmax >= M): a plan that does not fit returns -3
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-            float* ws, hipStream_t st, int background = 0);
+            float* ws, size_t ws_bytes, hipStream_t st, int background = 0);
 
 // attention.hip
 // launch-shape choices of the backward kernels (engine-owned, "attn_jq" / "attn_kw" / "attn_nch" options):
@@ -98,6 +99,13 @@ int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const fl
 int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
                double eps, double wd, int step, int zero_grad, hipStream_t st);
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st);
+// AdamW over `batch` same-shaped [R][C] matrices (64-multiples) at a constant stride that ALSO writes the transposed bf16
+// image pt[C][R]; mode 0 = fp32 master + fp32 moments, 1 = fp32 master + bf16 moments, 2 = bf16 parameters + bf16 moments.
+int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, void* v, int R, int C, int batch, size_t batch_stride,
+                const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
+// the same update on `batch` vectors of n elements at a constant stride (no transposed image)
+int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, size_t n, int batch, size_t stride, const float* clip,
+                  double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st);
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
                        int accumulate, hipStream_t st);

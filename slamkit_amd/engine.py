@@ -76,6 +76,8 @@ def load_library(path: Optional[str] = None):
         "slam_grad_norm": (C.c_int, [vp, f32, vp, vp]),
         "slam_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_adamw_step_bf16": (C.c_int, [vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_adamw_step_bf16_moments": (C.c_int, [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
+        "slam_adamw_range_bf16_moments": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_grad_chunk_elems": (i64, []),
         "slam_grad_sumsq_chunks": (C.c_int, [vp, i64, i64, vp, vp]),
         "slam_grad_norm_from_chunks": (C.c_int, [vp, vp, f32, vp, vp]),
@@ -240,6 +242,13 @@ class Engine:
 
     def adamw_step(self, master, exp_avg, exp_avg_sq, norm_out, lr, beta1, beta2, eps, weight_decay, step,
                    zero_grad=True, stream=None):
+        import torch
+        if exp_avg.dtype == torch.bfloat16:  # fp32 master + bf16 moments
+            self._ck(self.lib.slam_adamw_step_bf16_moments(self.h, _ptr(master), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(norm_out),
+                                                           float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                           int(step), int(bool(zero_grad)),
+                                                           stream if stream is not None else current_stream_ptr()))
+            return
         self._ck(self.lib.slam_adamw_step(self.h, _ptr(master), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(norm_out),
                                           float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                           int(step), int(bool(zero_grad)),
@@ -273,12 +282,18 @@ class Engine:
                     step, zero_grad=False, stream=None):
         """AdamW on elements [offset, offset + count): master / exp_avg / exp_avg_sq are FULL-SIZE flat tensors here (the
         range's slices are passed down); master = None selects the bf16-state form."""
+        import torch
         o, n = int(offset), int(count)
         st = stream if stream is not None else current_stream_ptr()
         if master is None:
             self._ck(self.lib.slam_adamw_range_bf16(self.h, o, n, _ptr(exp_avg[o:o + n]), _ptr(exp_avg_sq[o:o + n]), _ptr(norm_out),
                                                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                                     int(step), int(bool(zero_grad)), st))
+        elif exp_avg.dtype == torch.bfloat16:
+            self._ck(self.lib.slam_adamw_range_bf16_moments(self.h, o, n, _ptr(master[o:o + n]), _ptr(exp_avg[o:o + n]),
+                                                            _ptr(exp_avg_sq[o:o + n]), _ptr(norm_out), float(lr), float(beta1),
+                                                            float(beta2), float(eps), float(weight_decay), int(step),
+                                                            int(bool(zero_grad)), st))
         else:
             self._ck(self.lib.slam_adamw_range(self.h, o, n, _ptr(master[o:o + n]), _ptr(exp_avg[o:o + n]), _ptr(exp_avg_sq[o:o + n]),
                                                _ptr(norm_out), float(lr), float(beta1), float(beta2), float(eps),

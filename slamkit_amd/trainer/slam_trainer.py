@@ -47,16 +47,20 @@ class SLAMTrainer:
         dev = model.device
         n = model.engine.n_params
         osd = getattr(self.args, "optim_state_dtype", "float32") or "float32"
-        if osd not in ("float32", "bfloat16"):
-            raise ValueError(f"optim_state_dtype must be float32 or bfloat16, got {osd!r}")
-        self.state_dtype = getattr(torch, osd)
+        if osd not in ("float32", "bfloat16", "float32_bf16_moments"):
+            raise ValueError(f"optim_state_dtype must be float32, bfloat16 or float32_bf16_moments, got {osd!r}")
+        # state_dtype = precision of the WEIGHT state (fp32 master or the bf16 parameters themselves); moment_dtype = Adam moments
+        self.state_dtype = torch.bfloat16 if osd == "bfloat16" else torch.float32
+        self.moment_dtype = torch.float32 if osd == "float32" else torch.bfloat16
         if self.state_dtype == torch.bfloat16:
             if getattr(self.args, "overlap_optimizer", False):
                 raise ValueError("overlap_optimizer is implemented for the fp32-state optimizer only")
             if hasattr(model, "drop_master"):
                 model.drop_master()  # the bf16 parameters become the only copy (the recipe's torch_dtype: bfloat16)
-        self.exp_avg = torch.zeros(n, dtype=self.state_dtype, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=self.state_dtype, device=dev)
+        if self.moment_dtype == torch.bfloat16 and self.state_dtype == torch.float32 and getattr(self.args, "overlap_optimizer", False):
+            raise ValueError("overlap_optimizer is implemented for the fp32-state optimizer only")
+        self.exp_avg = torch.zeros(n, dtype=self.moment_dtype, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=self.moment_dtype, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         cd = getattr(self.args, "ddp_comm_dtype", None)
         algo = getattr(self.args, "ddp_algo", "all_reduce") or "all_reduce"

@@ -40,3 +40,16 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(OSError):
         E.load_library(str(tmp_path / "nope.so"))
+
+
+def test_gemm_tn_workspace_covers_every_contraction_length():
+    """The wgrad planners re-plan from the runtime token count (packed micro-batches vary): the workspace sized for Mmax must
+    cover the plan of every M <= Mmax (round-2 advisor finding: H 256, I 1024, Mmax 2048 - at M = 1600 the gate|up plan
+    needed 10.0 MiB of an 8.0 MiB allocation). Host-only: the sizing function does not touch the device."""
+    from slamkit_amd import engine as E
+    lib = E.load_library()
+    assert lib.slam_op_gemm_tn_workspace(2048, 2048, 256) >= 10 * 2 ** 20
+    for N, K in ((2048, 256), (9728, 896), (896, 4864), (1152, 896), (896, 896)):
+        cap = lib.slam_op_gemm_tn_workspace(8192, N, K)
+        for M in range(64, 8192 + 1, 64):
+            assert lib.slam_op_gemm_tn_workspace(M, N, K) <= cap, (M, N, K)

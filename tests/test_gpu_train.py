@@ -245,6 +245,63 @@ def test_adamw_bf16_state_step_vs_oracle():
     assert torch.equal(wt.t().contiguous(), dict(m.named_parameters())[k])
 
 
+@pytest.mark.parametrize("osd", ["float32", "bfloat16", "float32_bf16_moments"])
+def test_fused_adamw_writes_the_transposed_images(osd):
+    """The optimizer kernel that writes the transposed weight images itself (64 x 64 tiles through LDS) against the flat
+    kernel + separate transpose pass ("fuse_adamw_t" = 0): parameters, master weights, both moments and the transposed
+    images BIT-IDENTICAL after 3 steps, in all three state precisions; and the images equal a fresh transpose of the
+    parameters."""
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    cfg = O.TINY
+    sd = O.init_weights(cfg, seed=4, bias_std=0.02, norm_jitter=0.05)
+    res = []
+    for fused in (1, 0):
+        m = _tiny_model(sd)
+        assert m.flat_params_t is not None
+        m.engine.set_option("fuse_adamw_t", fused)
+        tr = SLAMTrainer(model=m, args=SLAMTrainingArguments(optim_state_dtype=osd, weight_decay=0.01, max_grad_norm=0.5, logging_steps=0))
+        gen = torch.Generator().manual_seed(0)
+        for step in range(3):
+            m.flat_grads.copy_(torch.randn(m.engine.n_params, generator=gen) * 1e-2)
+            tr._clip_and_update(1e-3, zero_grad=True)
+        torch.cuda.synchronize()
+        pt = m.flat_params_t.clone()
+        m.engine.refresh_transposed()
+        torch.cuda.synchronize()
+        assert torch.equal(pt, m.flat_params_t), f"fused={fused}: transposed images differ from a fresh transpose"
+        res.append((m.flat_params.clone(), m._weights.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), pt))
+    for a, b, name in zip(res[0], res[1], ("params", "weights", "exp_avg", "exp_avg_sq", "params_t")):
+        assert torch.equal(a, b), name
+
+
+def test_adamw_bf16_moments_step_vs_oracle():
+    """fp32 master + bf16 moments (22 B/param): 5 updates against the oracle's restatement; the master within fp32
+    contraction noise, the moments within a bf16 ulp or two."""
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    cfg = O.TINY
+    sd = O.init_weights(cfg, seed=4, bias_std=0.02, norm_jitter=0.05)
+    m = _tiny_model(sd)
+    tr = SLAMTrainer(model=m, args=SLAMTrainingArguments(optim_state_dtype="float32_bf16_moments", weight_decay=0.01, max_grad_norm=0.0,
+                                                         logging_steps=0))
+    n = m.engine.n_params
+    p = m.flat_master.detach().cpu().clone()
+    mo, vo = torch.zeros(n).bfloat16(), torch.zeros(n).bfloat16()
+    gen = torch.Generator().manual_seed(0)
+    for step in range(1, 6):
+        g = torch.randn(n, generator=gen) * 1e-2
+        m.flat_grads.copy_(g)
+        tr._clip_and_update(1e-3, zero_grad=True)
+        O.adamw_update_bf16_moments(p, g, mo, vo, step, 1e-3, wd=0.01)
+    torch.cuda.synchronize()
+    got = m.flat_master.cpu()
+    assert float((got - p).abs().max()) <= 2e-5 * float(p.abs().max()) + 1e-7, float((got - p).abs().max())
+    assert torch.equal(m.flat_params.cpu(), got.bfloat16())  # the working copy is the rounded master
+    for mine, ref in ((tr.exp_avg.cpu(), mo), (tr.exp_avg_sq.cpu(), vo)):
+        tol = 2.0 ** -5 * ref.float().abs() + 2e-3 * float(ref.float().abs().max())
+        err = (mine.float() - ref.float()).abs()
+        assert not bool((err > tol).any()), int((err > tol).sum())
+
+
 def test_overlapped_optimizer_is_bit_identical():
     """overlap_optimizer=True (AdamW in per-layer chunks on the engine's side stream, forward waits per layer) must give
     exactly the parameters of the in-order step."""
