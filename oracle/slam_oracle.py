@@ -178,14 +178,16 @@ def _bf16_round(x: torch.Tensor) -> torch.Tensor:
 
 
 def decoder_stack(cfg: OracleConfig, sd: Dict[str, torch.Tensor], h: torch.Tensor, E_head: torch.Tensor,
-                  attention_mask=None, position_ids=None, packed=False, bf16_acts: bool = False):
+                  attention_mask=None, position_ids=None, packed=False, bf16_acts: bool = False, collect: Optional[list] = None):
     """Qwen2Model layers + final norm + tied head on given input embeddings
     (hf: modeling_qwen2.py:342-402, DecoderLayer :269-298, Attention :189-233, MLP :41-48, head :465).
     bf16_acts=True restates the reference's OWN precision (bf16 parameters under bf16 autocast, slam.yaml:9 +
     training_args bf16): every module output the HF path materialises as a bf16 tensor - Linear outputs, RMSNorm
     outputs, rotated q / k, attention probabilities and output, the SwiGLU product, residual sums, logits - is rounded
     to bf16 at that point (arithmetic inside a module stays fp32, as the GPU kernels accumulate). Used to calibrate how
-    far ANY bf16 implementation sits from the fp32 run at a given depth / width (tests/test_gpu_model.py)."""
+    far ANY bf16 implementation sits from the fp32 run at a given depth / width (tests/test_gpu_model.py).
+    collect: list that receives HF's `output_hidden_states` tuple - the input of every decoder layer, then the output of
+    the final norm (tests/golden/make_golden_deep.py pins the emulation against the reference per depth)."""
     r = _bf16_round if bf16_acts else (lambda t: t)
     B, T, _ = h.shape
     hd, nH, nKV = cfg.head_dim, cfg.n_heads, cfg.n_kv_heads
@@ -195,6 +197,8 @@ def decoder_stack(cfg: OracleConfig, sd: Dict[str, torch.Tensor], h: torch.Tenso
     mask = attention_mask_bool(B, T, attention_mask, position_ids, packed)
     for l in range(cfg.n_layers):
         p = f"lm.model.layers.{l}."
+        if collect is not None:
+            collect.append(h.detach())
         x = r(rms_norm(h, sd[p + "input_layernorm.weight"], cfg.rms_eps))
         q = r(F.linear(x, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"])).view(B, T, nH, hd).transpose(1, 2)
         k = r(F.linear(x, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])).view(B, T, nKV, hd).transpose(1, 2)
@@ -208,15 +212,17 @@ def decoder_stack(cfg: OracleConfig, sd: Dict[str, torch.Tensor], h: torch.Tenso
         u = r(F.linear(x, sd[p + "mlp.up_proj.weight"]))
         h = r(h + r(F.linear(r(F.silu(g) * u), sd[p + "mlp.down_proj.weight"])))
     hf = r(rms_norm(h, sd["lm.model.norm.weight"], cfg.rms_eps))
+    if collect is not None:
+        collect.append(hf.detach())
     return r(F.linear(hf, E_head))  # tied lm_head, hf: modeling_qwen2.py:407,465
 
 
 def model_forward(cfg: OracleConfig, sd: Dict[str, torch.Tensor], input_ids: torch.Tensor,
                   attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-                  packed: bool = False, bf16_acts: bool = False):
+                  packed: bool = False, bf16_acts: bool = False, collect: Optional[list] = None):
     """UnitLM.forward -> Qwen2ForCausalLM.forward without labels (unit_lm.py:155-167)."""
     E = sd["lm.model.embed_tokens.weight"]
-    return decoder_stack(cfg, sd, F.embedding(input_ids, E), E, attention_mask, position_ids, packed, bf16_acts)
+    return decoder_stack(cfg, sd, F.embedding(input_ids, E), E, attention_mask, position_ids, packed, bf16_acts, collect)
 
 
 def compute_loss(logits: torch.Tensor, labels: torch.Tensor, num_items_in_batch=None, ignore_index: int = -100):

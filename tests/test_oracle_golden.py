@@ -1,6 +1,8 @@
 """The CPU oracle against the golden vectors captured from the real reference
 (tests/golden/make_golden.py). fp32 tolerances from SURVEY.md §8c: logits <= 1e-5 abs,
 loss <= 1e-6, grads <= 1e-5 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -221,3 +223,66 @@ def test_bf16_activation_emulation_matches_reference_autocast_noise(golden_npz, 
     dev = float((b[m] - a[m]).pow(2).mean().sqrt() / a[m].pow(2).mean().sqrt())
     ref = float(golden_npz["pad_logits_bf16_rmsrel"])
     assert 0.75 * ref <= dev <= 1.25 * ref, (dev, ref)
+
+
+# ---- depth anchor (round 3): the reference on a 12-layer model, fp32 and bf16-autocast (tests/golden/make_golden_deep.py) ----
+@pytest.fixture(scope="module")
+def deep_golden():
+    import ast
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "deep_model.npz"), allow_pickle=False)
+    meta = ast.literal_eval(str(z["meta"][0]))
+    cfg = O.OracleConfig(**meta["config"])
+    sd = O.init_weights(cfg, seed=meta["seed"], bias_std=meta["bias_std"], norm_jitter=meta["norm_jitter"])
+    return z, cfg, sd
+
+
+def test_oracle_matches_reference_at_depth_12(deep_golden):
+    """The fp32 oracle against the reference's fp32 run of a 12-layer model: logits, loss, every gradient tensor's norm and
+    16 samples of each - the restatement holds at depth, not only on the 2-layer golden model."""
+    z, cfg, sd = deep_golden
+    ids, am, labels = (torch.from_numpy(z[k]) for k in ("ids", "mask", "labels"))
+    loss, logits, grads = O.forward_loss_grads(cfg, sd, ids, labels, attention_mask=am)
+    ref = torch.from_numpy(z["logits_fp32"])
+    m = am.bool()
+    assert float((logits[m] - ref[m]).abs().max()) <= 2e-5 * float(ref[m].abs().max())
+    assert abs(float(loss) - float(z["loss_fp32"])) <= 2e-6
+    for k, n in zip(z["grad_names"].tolist(), z["grad_norm_fp32"].tolist()):
+        g = grads[k]
+        assert abs(float(g.norm()) - n) <= 2e-5 * n + 1e-9, k
+        flat = g.flatten()
+        samp = flat[torch.linspace(0, flat.numel() - 1, 16).long()]
+        assert float((samp - torch.from_numpy(z["gradsample/" + k])).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-9, k
+
+
+def test_bf16_emulation_tracks_reference_autocast_per_depth(deep_golden):
+    """The yard-stick of the deep-model GPU tests, anchored on the reference AT DEPTH: the oracle's `bf16_acts` emulation
+    (bf16 parameters, bf16 tensors between modules) must sit as far from the fp32 run as the reference's own bf16-autocast
+    run does - hidden states after every decoder layer within 30 %, logits within 25 %, and its gradients must be no closer
+    to / no further from the fp32 gradients than a factor of two in (1 - cosine). The GPU bars "<= k x emulation" are
+    therefore bars "<= 1.3 k x what the reference's own training precision deviates"."""
+    z, cfg, sd = deep_golden
+    ids, am, labels = (torch.from_numpy(z[k]) for k in ("ids", "mask", "labels"))
+    m = am.bool()
+    sdb = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    h32, h16 = [], []
+    with torch.no_grad():
+        a = O.model_forward(cfg, sd, ids, attention_mask=am, collect=h32)
+        b = O.model_forward(cfg, sdb, ids, attention_mask=am, bf16_acts=True, collect=h16)
+    rel = lambda x, y: float((x[m] - y[m]).pow(2).mean().sqrt() / y[m].pow(2).mean().sqrt())  # noqa: E731
+    ref_h = z["hidden_bf16_relrms"].tolist()
+    assert len(h32) == len(ref_h) == cfg.n_layers + 1
+    devs = [rel(x, y) for x, y in zip(h16, h32)]
+    print("[anchor] hidden-state deviation per depth: emulation", [round(d, 5) for d in devs], "reference", [round(d, 5) for d in ref_h])
+    for d, (e, r) in enumerate(zip(devs, ref_h)):
+        assert 0.7 * r <= e <= 1.3 * r, (d, e, r)
+    dl, rl = rel(b, a), float(z["logits_bf16_relrms"])
+    assert 0.75 * rl <= dl <= 1.25 * rl, (dl, rl)
+    _, _, g32 = O.forward_loss_grads(cfg, sd, ids, labels, attention_mask=am)
+    _, _, g16 = O.forward_loss_grads(cfg, sdb, ids, labels, attention_mask=am, bf16_acts=True)
+    cos = lambda x, y: float((x.flatten().double() @ y.flatten().double()) / (x.norm().double() * y.norm().double() + 1e-30))  # noqa: E731
+    names, ref_c = z["grad_names"].tolist(), z["grad_cos_bf16_vs_fp32"].tolist()
+    mat = [(k, 1 - cos(g16[k], g32[k]), 1 - c) for k, c in zip(names, ref_c) if k.endswith("proj.weight") or "embed" in k]
+    worst_e, worst_r = max(e for _, e, _ in mat), max(r for _, _, r in mat)
+    print(f"[anchor] worst matrix-gradient 1 - cos: emulation {worst_e:.2e}, reference {worst_r:.2e}")
+    assert 0.5 * worst_r <= worst_e <= 2.0 * worst_r, (worst_e, worst_r)
