@@ -4,6 +4,8 @@
 //   RMSNorm :247-252, RoPE :91-135, SwiGLU :41-48, embedding :356;
 // loss: /root/reference slamkit/model/unit_lm.py:13-29; optimizer: torch AdamW + HF
 // clip_grad_norm_.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -783,18 +785,19 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p,
 // tile is one contiguous 256 B (fp32) / 128 B (bf16) piece of each state array; the updated bf16 tile goes out row-major
 // (pb) and, through a padded LDS tile, column-major (pt[C][R]). Per-element arithmetic is the flat kernels' own.
 // MT = float / bf16_t: storage type of the Adam moments; MASTER: fp32 master weights (else the bf16 parameters ARE the state).
-template <typename MT, bool MASTER>
+template <typename MT, bool MASTER, int TC>  // tile = 64 rows x TC columns (TC = 64 or 128: 256 B or 512 B fp32 row segments)
 __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, bf16_t* __restrict__ pt,
                                                          float* __restrict__ g, MT* __restrict__ m, MT* __restrict__ v, int R, int C,
                                                          size_t batch_stride, const float* __restrict__ clip, AdamHyper h) {
-  __shared__ uint16_t T[64][66];  // transposed bf16 tile: T[col][row], rows padded to 132 B
+  constexpr int TPR = TC / 4, RPP = 256 / TPR, NP = 64 / RPP;  // threads per row, rows per pass, passes
+  __shared__ uint16_t T[TC][66];  // transposed bf16 tile: T[col][row], rows padded to 132 B
   const size_t boff = (size_t)blockIdx.z * batch_stride;
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tid = threadIdx.x, rr = tid >> 4, cc = (tid & 15) * 4;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * TC;
+  const int tid = threadIdx.x, rr = tid / TPR, cc = (tid % TPR) * 4;
   const float cs = clip ? clip[1] : 1.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = rr + 16 * i;
+  for (int i = 0; i < NP; ++i) {
+    const int row = rr + RPP * i;
     const size_t idx = boff + (size_t)(r0 + row) * C + c0 + cc;
     float ga[4], pa[4], ma[4], va[4];
     load4<float>(g + idx, ga);
@@ -813,12 +816,15 @@ __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, 
     for (int j = 0; j < 4; ++j) T[cc + j][row] = (uint16_t)(pack_bf16x2(pa[j], 0.f) & 0xffffu);
   }
   __syncthreads();
-  const int orow = tid >> 2, seg = (tid & 3) * 16;  // transposed row c0 + orow, its 16 elements r0 + seg ..
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(&T[orow][seg]);
-  uint4 a = make_uint4(src[0], src[1], src[2], src[3]), b = make_uint4(src[4], src[5], src[6], src[7]);
-  bf16_t* dst = pt + boff + (size_t)(c0 + orow) * R + r0 + seg;
-  *reinterpret_cast<uint4*>(dst) = a;
-  *reinterpret_cast<uint4*>(dst + 8) = b;
+#pragma unroll
+  for (int q = 0; q < TC / 64; ++q) {
+    const int orow = q * 64 + (tid >> 2), seg = (tid & 3) * 16;  // transposed row c0 + orow, its 16 elements r0 + seg ..
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&T[orow][seg]);
+    uint4 a = make_uint4(src[0], src[1], src[2], src[3]), b = make_uint4(src[4], src[5], src[6], src[7]);
+    bf16_t* dst = pt + boff + (size_t)(c0 + orow) * R + r0 + seg;
+    *reinterpret_cast<uint4*>(dst) = a;
+    *reinterpret_cast<uint4*>(dst + 8) = b;
+  }
 }
 // the vectors between the matrices (norm weights, biases): count elements at a constant stride, grid.y = instances
 template <typename MT, bool MASTER>
@@ -1067,10 +1073,20 @@ int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, v
                 const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
   if ((R & 63) || (C & 63) || batch < 1 || mode < 0 || mode > 2) return -1;
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, step, zero_grad);
-  const dim3 grid(C / 64, R / 64, batch);
-  if (mode == 0) adamw_tile_kernel<float, true><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
-  else if (mode == 1) adamw_tile_kernel<bf16_t, true><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
-  else adamw_tile_kernel<bf16_t, false><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  static int tile_cols = 128;  // SLAM_ADAMW_TILE_COLS=64: 256-byte row segments (A/B knob)
+  static bool read_env = false;
+  if (!read_env) { const char* e = getenv("SLAM_ADAMW_TILE_COLS"); if (e && atoi(e) == 64) tile_cols = 64; read_env = true; }
+  if (tile_cols == 128 && (C % 128 == 0)) {
+    const dim3 grid(C / 128, R / 64, batch);
+    if (mode == 0) adamw_tile_kernel<float, true, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
+    else if (mode == 1) adamw_tile_kernel<bf16_t, true, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+    else adamw_tile_kernel<bf16_t, false, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  } else {
+    const dim3 grid(C / 64, R / 64, batch);
+    if (mode == 0) adamw_tile_kernel<float, true, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
+    else if (mode == 1) adamw_tile_kernel<bf16_t, true, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+    else adamw_tile_kernel<bf16_t, false, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  }
   LAUNCH_RET();
 }
 int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, size_t n, int batch, size_t stride, const float* clip,

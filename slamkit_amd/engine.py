@@ -109,6 +109,8 @@ def load_library(path: Optional[str] = None):
         "slam_op_embed_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     }
     for name, (res, args) in sig.items():
+        if path is not None and not hasattr(lib, name):
+            continue  # an explicitly named OTHER build (A/B tooling against an older library): bind what it has
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -11,9 +11,8 @@ from tests.gpu_util import cosine
 pytestmark = pytest.mark.gpu
 
 
-def _model(sd, max_tokens=2048):
+def _model(sd, max_tokens=2048, cfg=O.TINY):
     from slamkit_amd.model import UnitLM, UnitLMConfig
-    cfg = O.TINY
     base = dict(num_hidden_layers=cfg.n_layers, hidden_size=cfg.hidden, num_attention_heads=cfg.n_heads,
                 num_key_value_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate,
                 rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=True)
@@ -38,22 +37,25 @@ def _pairs(n=4, seed=0):
              "rejected": mk(int(torch.randint(50, 150, (1,), generator=g)))} for _ in range(n)]
 
 
-def test_dpo_loss_and_grads_vs_oracle():
+@pytest.mark.parametrize("shape", ["tiny", "slam358m"])
+def test_dpo_loss_and_grads_vs_oracle(shape):
+    """tiny: 4 pairs on the 2-layer model. slam358m: BASELINE.json configs[4] at its own shape - 8 preference pairs (16
+    sequences) on the full Slam-358M body, policy forward + backward and reference forward against the fp32 oracle; every
+    gradient tensor at the Slam-358M bars of test_gpu_model.py (matrices >= 0.999, bias / norm vectors >= 0.99)."""
     from slamkit_amd.tokeniser import UnitTokeniser
     from slamkit_amd.trainer import DPOConfig, SLAMDPOTrainer
-    cfg = O.TINY
+    cfg, n, big, small_bar = (O.TINY, 4, 0.995, 0.98) if shape == "tiny" else (O.SLAM_358M, 8, 0.999, 0.99)
     sd_pol = O.init_weights(cfg, seed=11, bias_std=0.02)
     sd_ref = O.init_weights(cfg, seed=12, bias_std=0.02)
-    pol, ref = _model(sd_pol), _model(sd_ref)
+    pol, ref = _model(sd_pol, 16 * 256, cfg), _model(sd_ref, 16 * 256, cfg)
     tok = UnitTokeniser(None, load_fe=False)
-    args = DPOConfig(per_device_train_batch_size=4, beta=0.1, logging_steps=1, max_steps=1, output_dir="/tmp/unused",
+    args = DPOConfig(per_device_train_batch_size=n, beta=0.1, logging_steps=1, max_steps=1, output_dir="/tmp/unused",
                      learning_rate=5e-5, warmup_steps=0, warmup_ratio=0.0)
-    tr = SLAMDPOTrainer(model=pol, ref_model=ref, args=args, train_dataset=_pairs(4), processing_class=tok)
-    mb = tr._collate_pairs(tr.train_dataset[:4])
+    tr = SLAMDPOTrainer(model=pol, ref_model=ref, args=args, train_dataset=_pairs(n), processing_class=tok)
+    mb = tr._collate_pairs(tr.train_dataset[:n])
     ids, lab = mb["input_ids"], mb["labels"]
-    n = 4
     # config-5 shapes (SURVEY.md §8d): prompt 25..75, completions 50..150 unit tokens (+ bos / eos)
-    assert ids.shape[0] == 8 and int((lab[:, 0] == -100).all()) == 1
+    assert ids.shape[0] == 2 * n and int((lab[:, 0] == -100).all()) == 1
 
     # --- engine ---
     pol.zero_grad()
@@ -79,6 +81,7 @@ def test_dpo_loss_and_grads_vs_oracle():
     assert torch.allclose(lp.cpu(), o_pol.detach(), rtol=2e-3, atol=0.3), (lp.cpu(), o_pol)
     assert torch.allclose(ref_lp.cpu(), o_ref, rtol=2e-3, atol=0.3)
     assert abs(float(losses.mean()) - float(o_loss)) <= 2e-2
+    worst = {False: 1.0, True: 1.0}
     for k, gv in pol.named_grads():
         if k == "lm.model.embed_tokens.weight":
             ref_g = pw[k].grad.clone()
@@ -86,7 +89,10 @@ def test_dpo_loss_and_grads_vs_oracle():
             ref_g = pw[k].grad
         small = k.endswith(".bias") or k.endswith("norm.weight")
         c = cosine(gv, ref_g)
-        assert c >= (0.98 if small else 0.995), f"{k}: cosine {c:.4f}"
+        worst[small] = min(worst[small], c)
+        assert c >= (small_bar if small else big), f"{k}: cosine {c:.4f}"
+    print(f"[parity] DPO {shape}: loss engine/oracle {float(losses.mean()):.5f} / {float(o_loss):.5f}, worst gradient cosine "
+          f"matrices {worst[False]:.5f}, vectors {worst[True]:.5f}")
 
 
 def test_dpo_trainer_reduces_preference_loss():

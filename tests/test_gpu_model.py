@@ -309,6 +309,11 @@ def test_slam358m_loss_and_grads_vs_oracle():
     m.backward()
     l8 = float(o8.loss)
     assert math.isfinite(l8) and abs(l8 - math.log(502)) < 0.5
+    # the BASELINE shape itself against the oracle (forward only: 8 x 1024 tokens of fp32 CPU work)
+    with torch.no_grad():
+        loss8_ref = float(O.compute_loss(O.model_forward(cfg, sd_bf, ids8), ids8))
+    print("slam358m B=8 T=1024 loss engine/oracle", l8, loss8_ref)
+    assert abs(l8 - loss8_ref) <= 2e-2
     assert bool(torch.isfinite(m.flat_grads).all())
     g8 = m.flat_grads.clone()
     # batch-row permutation leaves the token-mean loss and the summed gradient unchanged
