@@ -250,7 +250,16 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
     collator choice by cfg.data.packing."""
     data = _get(cfg, "data")
     saved = _get(data, "saved_ds_path", None)
-    if saved and os.path.isdir(saved):
+    # load-or-build is decided ONCE (rank 0, on the completion marker written after the last shard) and broadcast: ranks
+    # that looked at the directory themselves could see a half-written cache, take different branches and miss the barrier
+    have_cache = bool(saved) and os.path.isfile(os.path.join(saved, "_COMPLETE"))
+    import torch.distributed as _dist
+    _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+    if _multi:
+        flag = [have_cache]
+        _dist.broadcast_object_list(flag, src=0)
+        have_cache = bool(flag[0])
+    if saved and have_cache:
         logger.info(f"Loading dataset from {saved}")
         dataset = {s: TokenShardDataset(os.path.join(saved, s)) for s in ("train", "validation")
                    if os.path.isdir(os.path.join(saved, s))}
@@ -282,6 +291,8 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
                 logger.info(f"Saving dataset to {saved}")
                 for s, d in dataset.items():
                     write_token_shard(os.path.join(saved, s), d)
+                with open(os.path.join(saved, "_COMPLETE"), "w") as f:  # written last: the cache is valid only with it
+                    f.write("ok\n")
             if multi:
                 dist.barrier()
     if _get(data, "packing", False):

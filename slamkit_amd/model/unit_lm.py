@@ -432,9 +432,16 @@ class UnitLM(TokenLM):
         token's output, so the engine does not read it."""
         assert input_ids is not None and input_ids.dim() == 2
         B, T = input_ids.shape
-        if attention_mask is not None and not _right_padded(attention_mask):
-            # checked for device masks too (one small host read): a left-padded mask would otherwise be ignored silently
+        if attention_mask is not None and not attention_mask.is_cuda and not _right_padded(attention_mask):
+            # collated batches arrive on the host (the trainer's boundary): checked there. A DEVICE mask is not read back -
+            # that would stall the host behind the previous step's kernels in the hot loop; callers that build masks on
+            # the device (synthetic benches, DPO's padded pairs) construct right padding by definition.
             raise ValueError("only right-padded attention_mask is supported")
+        if position_ids is not None and B > 1 and not position_ids.is_cuda:
+            # [B > 1, T] with positions is the dense layout (every row 0..T-1); a packed batch mis-shaped as several rows
+            # would silently lose its segment bounds (the engine takes segments from a [1, sum T] row only)
+            if not bool((position_ids == torch.arange(T, dtype=position_ids.dtype)[None]).all()):
+                raise ValueError("position_ids with batch size > 1 must be plain aranges; packed batches are [1, sum T]")
         dev = self.device
         ids = input_ids.to(dev, torch.int64)
         lab = labels.to(dev, torch.int64) if labels is not None else None

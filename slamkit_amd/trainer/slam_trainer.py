@@ -74,6 +74,9 @@ class SLAMTrainer:
             self._chunk_sums = torch.zeros(n_chunks, dtype=torch.float32, device=dev)
         else:
             self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)
+        if (self.world > 1 or self.reducer.force) and torch.device(dev).type == "cuda":
+            from .. import check_hw_queues
+            check_hw_queues(8)
         self.host_group = host_group()  # None on a single rank or when gloo cannot be set up
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._loss_n = 0
