@@ -335,6 +335,12 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
           for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
       }
     }
+    // the V^T fragments of the first contraction half are requested BEFORE the exp / pack arithmetic and land under it
+    // (left to itself the compiler sinks every fragment read to just before its MFMA pair: eight exposed LDS latencies)
+    uint4 vf0[4 * ND];
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd) vf0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
     uint4 pb[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -352,14 +358,18 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
       pb[0][j] = pack_pair(st[0][j], st[1][j]);
       pb[1][j] = pack_pair(st[2][j], st[3][j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 vf1[4 * ND];  // second half: requested before the first half's MFMAs
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int fd = 0; fd < 4 * ND; ++fd) vf1[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 1);
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd) {
-        uint4 vf = ta.T((ND + (fd >> 2)) * IMG, fd & 3, t2);
+    for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf, pb[t2][j], ot[fd][j]);
-      }
+      for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf0[fd], pb[0][j], ot[fd][j]);
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf1[fd], pb[1][j], ot[fd][j]);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -537,16 +547,24 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
         dsb[1][j] = pack_pair(st[2][j], st[3][j]);
       }
     };
+    uint4 kt0[4 * ND];  // K^T fragments of the first contraction half: requested before the exp arithmetic, landing under it
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd) kt0[fd] = ta.T((fd >> 2) * IMG, fd & 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if ((key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + WR - 1 >= M)) soft(std::true_type{});
     else soft(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 kt1[4 * ND];
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int fd = 0; fd < 4 * ND; ++fd) kt1[fd] = ta.T((fd >> 2) * IMG, fd & 3, 1);
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd) {
-        const uint4 kt = ta.T((fd >> 2) * IMG, fd & 3, t2);
+    for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
-        for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt, dsb[t2][j], dq[j][fd]);
-      }
+      for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt0[fd], dsb[0][j], dq[j][fd]);
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+      for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt1[fd], dsb[1][j], dq[j][fd]);
   }
 #pragma unroll
   for (int j = 0; j < JQ; ++j) {
@@ -770,13 +788,21 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
     };
     // latest segment start among the tile's query rows: row 63's (rows beyond M repeat row M-1)
     const int segmax = *(__attribute__((address_space(3))) const int*)(lds_p(sb + (uint32_t)(2 * ND * IMG + 512 + 63 * 4)));
+    constexpr bool PF = KW == 1;  // (32 keys per wave: no registers left for it)
+    uint4 dot0[4 * ND];  // dO^T fragments of the first contraction half: requested before the exp arithmetic
+    if constexpr (PF) {
+#pragma unroll
+      for (int fd = 0; fd < 4 * ND; ++fd) dot0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if ((kw0 + WK - 1 > qbase) || (kw0 < segmax) || (qbase + 63 >= M)) soft(std::true_type{});
     else soft(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int fd = 0; fd < 4 * ND; ++fd) {
-        const uint4 dot = ta.T((ND + (fd >> 2)) * IMG, fd & 3, t2);
+        const uint4 dot = (PF && t2 == 0) ? dot0[fd] : ta.T((ND + (fd >> 2)) * IMG, fd & 3, t2);
         const uint4 qt = ta.T((fd >> 2) * IMG, fd & 3, t2);
 #pragma unroll
         for (int i = 0; i < KW; ++i) {

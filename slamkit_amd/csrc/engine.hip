@@ -926,7 +926,12 @@ int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, 
 size_t slam_op_gemm_tn_workspace(int M, int N, int K) { return gemm_tn_workspace_bytes(M, N, K); }
 int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,
                     slam_stream_t s) {
-  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, gemm_tn_workspace_bytes(M, N, K), (hipStream_t)s);
+  // capacity = what slam_op_gemm_tn_workspace(M, N, K) promises (the caller's contract; recomputing the bound here would put
+  // a host-side planning sweep into every launch)
+  static int cm = 0, cn = 0, ck = 0;
+  static size_t cap = 0;
+  if (cm != M || cn != N || ck != K) { cap = gemm_tn_workspace_bytes(M, N, K); cm = M; cn = N; ck = K; }
+  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, cap, (hipStream_t)s);
 }
 int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s) {
   return rmsnorm_fwd((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, M, H, eps, (hipStream_t)s);
