@@ -48,6 +48,7 @@ struct AttnArgs {
   bf16_t* dqkv;        // [M][ldq]
   float* lse2;         // [nH][M]  log2-domain logsumexp of scaled scores
   float* ndsum;        // [nH][M]  -rowsum(dO*O)
+  float* nlse;         // [nH][M]  -lse2 (written by the dQ kernel: the dK/dV kernel starts its score accumulators there)
   float* dkv_part;     // [NCH_MAX][2][nKV][M][D] fp32 dK / dV partials per query-range chunk
   const int* seg_start;  // [M]
   const int* seg_end;    // [M]
@@ -143,6 +144,15 @@ struct TileAddr {
   }
 };
 
+// bf16x8 fragment times a scalar (fp32 product, rounded once): the register-resident operand of the score MFMAs carries
+// the softmax scale * log2(e), so a score comes out of the matrix pipe already in the exp2 domain
+SLAM_DEVICE uint4 scale_frag(const uint4& v, float c) {
+  float f[8];
+  unpack_bf16x8(v, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] *= c;
+  return pack_bf16x8(f);
+}
 SLAM_DEVICE uint4 pack_pair(const f32x4_t& a, const f32x4_t& b) {
   return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
                     pack_bf16x2(b[2], b[3]));
@@ -252,15 +262,25 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
     segs[j] = p.seg_start[qc];
 #pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds)
-      qf[j][ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
+      qf[j][ds] = scale_frag(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds), c2);
   }
   const int segmax_w = p.seg_start[min(qw0 + 31, M - 1)];  // latest segment start among the wave's rows
-  f32x4_t ot[4 * ND][2];
+  // Instruction diet of the tile loop (a SIMD issues about one instruction per 5-6 cycles in this mix, so the loop is
+  // bound by its instruction COUNT - measured, tools/probes/ubench.hip): (1) the queries are pre-scaled by scale*log2(e)
+  // and the score accumulators START at -m (the running max, as a persistent register quad per row block), so a score
+  // leaves the matrix pipe as (s - m) in the exp2 domain and the probability is ONE v_exp_f32 - no fma, no per-tile
+  // multiply of the max; (2) the row sums run on the matrix pipe too (a ones fragment times P^T: every lane ends up
+  // with its row's sum, no adds, no final shuffle) - they sum the bf16-rounded probabilities the PV product uses.
+  f32x4_t ot[4 * ND][2], lacc[2], negm[2];
 #pragma unroll
-  for (int fd = 0; fd < 4 * ND; ++fd)
+  for (int j = 0; j < 2; ++j) {
+    lacc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    negm[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};  // m = 0 until the row has seen its first visible key ("started")
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float mrun[2] = {M_INIT, M_INIT}, lsum[2] = {0.f, 0.f};  // running max in raw-score units
+    for (int fd = 0; fd < 4 * ND; ++fd) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  bool started[2] = {false, false};
+  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 x 8
   wait_all_loads_visible();
 
   int stage = 0, istage = (NST - 1) % NST;
@@ -279,16 +299,12 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
     ta.set(fo, sb);
     f32x4_t st[4][2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         uint4 kf = ta.D((ds >> 1) * IMG, f, ds & 1);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], st[f][j]);
+        for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], ds == 0 ? negm[j] : st[f][j]);
       }
     if ((key0 + 63 > qw0) || (key0 < segmax_w)) {  // wave-uniform: diagonal or segment-boundary tile
 #pragma unroll
@@ -303,10 +319,11 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
           }
       }
     }
-    // Deferred running max (threshold 8 in the exp2 domain, P <= 256): the running max of a row is only raised - with
-    // the cross-lane reduction, the exp of the correction and the rescale of O - when some element of the tile exceeds
-    // it by more than the threshold. The test is lane-local (each lane checks its own 16 scores against the shared
-    // max) and wave-uniform via a ballot, so the common tile has no shuffles and no dependent chain through LDS.
+    // Deferred running max: the scores are already relative to m; m moves - with the cross-lane reduction, the exp of the
+    // correction, the rescale of O and l and the shift of this tile's scores - only when a score exceeds it by more than
+    // 8 (P <= 256), or on the first tile in which the row sees a key at all (then m becomes the true row max: a row
+    // whose scores all sit far below zero must not underflow against m = 0). The test is lane-local and wave-uniform
+    // via a ballot, so the common tile has no shuffles and no dependent chain.
     float mloc[2];
     bool grow = false;
 #pragma unroll
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
       mloc[j] = mx;
-      grow |= (mx - mrun[j]) * c2 > 8.0f;
+      grow |= (mx > 8.0f) | (!started[j] & (mx > 0.5f * NEG_BIG));
     }
     if (__any(grow)) {
 #pragma unroll
@@ -325,14 +342,21 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
         float mx = mloc[j];
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun[j], mx);
-        const float alpha = fast_exp2((mrun[j] - mnew) * c2);
-        mrun[j] = mnew;
-        lsum[j] *= alpha;
+        if (mx > 0.5f * NEG_BIG) {  // the row sees a key in this tile (the same for the four lanes of a row)
+          const float shift = started[j] ? -fmaxf(mx, 0.f) : -mx;  // m_old - m_new: m grows by max(mx, 0) once started; becomes the true max before
+          const float alpha = started[j] ? fast_exp2(shift) : 1.f;  // (nothing accumulated yet before the first key: exp2(-mx) may be inf)
+          started[j] = true;
 #pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd)
+          for (int r = 0; r < 4; ++r) { negm[j][r] += shift; lacc[j][r] *= alpha; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+          for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[f][j][r] += shift;
+        }
       }
     }
     // the V^T fragments of the first contraction half are requested BEFORE the exp / pack arithmetic and land under it
@@ -344,17 +368,10 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
     uint4 pb[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float mc = mrun[j] * c2;
-      float ps = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = fast_exp2(fmaf(st[f][j][r], c2, -mc));  // masked entries (NEG_BIG) underflow to exactly 0
-          st[f][j][r] = e;
-          ps += e;
-        }
-      lsum[j] += ps;
+        for (int r = 0; r < 4; ++r) st[f][j][r] = fast_exp2(st[f][j][r]);  // masked entries (NEG_BIG) underflow to exactly 0
       pb[0][j] = pack_pair(st[0][j], st[1][j]);
       pb[1][j] = pack_pair(st[2][j], st[3][j]);
     }
@@ -363,9 +380,13 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
 #pragma unroll
     for (int fd = 0; fd < 4 * ND; ++fd) vf1[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 1);
 #pragma unroll
+    for (int j = 0; j < 2; ++j) lacc[j] = mfma16(ones, pb[0][j], lacc[j]);
+#pragma unroll
     for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
       for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf0[fd], pb[0][j], ot[fd][j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lacc[j] = mfma16(ones, pb[1][j], lacc[j]);
 #pragma unroll
     for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
@@ -373,9 +394,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    float l = lsum[j];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = lacc[j][0];  // every lane of the row holds the full sum
     const int q = qrow[j];
     if (q < M) {
       const float inv = 1.f / l;
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
         o.y = pack_bf16x2(ot[fd][j][2] * inv, ot[fd][j][3] * inv);
         *reinterpret_cast<uint2*>(p.o + (size_t)q * (p.nH * D) + h * D + fd * 16 + g * 4) = o;
       }
-      if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = mrun[j] * c2 + log2f(l);
+      if (g == 0 && p.lse2) p.lse2[(size_t)h * M + q] = log2f(l) - negm[j][0];
     }
   }
 }
@@ -463,11 +482,11 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
     const int qc = q < M ? q : M - 1;
     qrow[j] = q;
     segs[j] = p.seg_start[qc];
-    lse[j] = p.lse2[(size_t)h * M + qc];
+    lse[j] = -p.lse2[(size_t)h * M + qc];  // kept negated: the score accumulators start there
     float dsm = 0.f;  // D[q] = sum_d dO[q][d] * O[q][d]: each lane owns a quarter of the d's, 4 lanes per row
 #pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds) {
-      qf[j][ds] = *reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds);
+      qf[j][ds] = scale_frag(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * ld + g * 8 + 32 * ds), c2);  // exp2-domain scores
       dof[j][ds] = *reinterpret_cast<const uint4*>(p.d_o + (size_t)qc * p.nH * D + h * D + g * 8 + 32 * ds);
       uint4 of = *reinterpret_cast<const uint4*>(p.o + (size_t)qc * p.nH * D + h * D + g * 8 + 32 * ds);
       float x[8], y[8];
@@ -479,7 +498,10 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
     dsm += __shfl_xor(dsm, 16, 64);
     dsm += __shfl_xor(dsm, 32, 64);
     nds[j] = -dsm;
-    if (g == 0 && q < M) p.ndsum[(size_t)h * M + q] = -dsm;  // consumed by the dK/dV kernel (launched after this one)
+    if (g == 0 && q < M) {  // consumed by the dK/dV kernel (launched after this one)
+      p.ndsum[(size_t)h * M + q] = -dsm;
+      p.nlse[(size_t)h * M + q] = lse[j];
+    }
   }
   const int segmax_w = p.seg_start[min(qw0 + WR - 1, M - 1)];
   f32x4_t dq[JQ][4 * ND];
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int j = 0; j < JQ; ++j) {
-        st[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        st[f][j] = (f32x4_t){lse[j], lse[j], lse[j], lse[j]};  // s - lse for free (pre-scaled queries): P = exp2(accumulator)
         dp[f][j] = (f32x4_t){nds[j], nds[j], nds[j], nds[j]};  // dP - D for free: the accumulator starts at -D[q]
       }
 #pragma unroll
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pe = fast_exp2(fmaf(st[f][j][r], c2, -lse[j]));
+            float pe = fast_exp2(st[f][j][r]);
             if constexpr (MASK) {
               const bool ok = (f * 16 + r <= hi) & (f * 16 + r >= lo);
               pe = ok ? pe : 0.f;
@@ -603,7 +625,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
 // dK / dV. One block = (64 KW-key tile, KV head, query-range chunk); wave w owns keys k0 + 16 KW w .. (KW 16-key
 // fragments, K and V rows in registers for the whole block). The block walks the G query heads of the KV group and, per
 // head, the 64-row query tiles of its chunk: Q and dO tiles stream through the ring (one image each, read both ways), dK
-// and dV accumulate over ALL of it in registers. Stage = Q image + dO image (16 KB per 64 head-dim columns) + lse2 /
+// and dV accumulate over ALL of it in registers. Stage = Q image + dO image (16 KB per 64 head-dim columns) + -lse2 /
 // -D / seg_start of the 64 query rows (3 x 256 B, by 4-byte LDS-DMA): 5 DMAs per lane per tile at head_dim 64.
 template <int ND, int KW>
 struct DkvCfg {
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
     // (the three sources are chosen from loop-invariant bases: a select between loop-carried pointers becomes a lookup
     //  table in scratch memory, and scratch traffic would also break the counted vmcnt waits)
     const size_t hrow = (size_t)i_head * M + irow;
-    const void* src = wv == 0 ? (const void*)(p.lse2 + hrow) : wv == 1 ? (const void*)(p.ndsum + hrow) : (const void*)(p.seg_start + irow);
+    const void* src = wv == 0 ? (const void*)(p.nlse + hrow) : wv == 1 ? (const void*)(p.ndsum + hrow) : (const void*)(p.seg_start + irow);
     glds4_m0(src, (uint32_t)(lane < mr ? lane : mr) * 4u, sdst + (uint32_t)(istage * STG));
     qp += qstep; dop += ostep; irow += 64;
     if (++i_tq == nq) {  // next head of the group: back to the chunk's first query tile
@@ -700,7 +722,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
     const int kc = key[i] < M ? key[i] : M - 1;
 #pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds) {
-      kf[i][ds] = *reinterpret_cast<const uint4*>(Kb + (size_t)kc * ld + g * 8 + 32 * ds);
+      kf[i][ds] = scale_frag(*reinterpret_cast<const uint4*>(Kb + (size_t)kc * ld + g * 8 + 32 * ds), c2);  // exp2-domain scores
       vf[i][ds] = *reinterpret_cast<const uint4*>(Vb + (size_t)kc * ld + g * 8 + 32 * ds);
     }
   }
@@ -730,9 +752,10 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
     f32x4_t s[4][KW], dp[4][KW];
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) {
+      const f32x4_t nl4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + jq * 64);
       const f32x4_t nd4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + (256 + jq * 64));
 #pragma unroll
-      for (int i = 0; i < KW; ++i) { s[jq][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[jq][i] = nd4; }  // dP - D for free
+      for (int i = 0; i < KW; ++i) { s[jq][i] = nl4; dp[jq][i] = nd4; }  // s - lse and dP - D for free: the accumulators start there
     }
 #pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds)
@@ -758,7 +781,6 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
       }
 #pragma unroll
       for (int jq = 0; jq < 4; ++jq) {
-        const f32x4_t l4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + jq * 64);
         int sv[4] = {0, 0, 0, 0};
         if constexpr (MASK) {
           typedef __attribute__((ext_vector_type(4))) int i32x4_t;
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
         for (int i = 0; i < KW; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pe = fast_exp2(fmaf(s[jq][i][r], c2, -l4[r]));
+            float pe = fast_exp2(s[jq][i][r]);
             if constexpr (MASK) {
               const bool ok = (jq * 16 + r >= lo[i]) & (jq * 16 + r < mh) & (key[i] >= sv[r]);
               pe = ok ? pe : 0.f;
@@ -968,14 +990,14 @@ size_t attn_bwd_workspace_bytes(int M, int nKV, int head_dim) {
   return (size_t)NCH_MAX * 2 * nKV * M * head_dim * sizeof(float);
 }
 
-int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* ndsum,
+int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* ndsum, float* nlse,
              bf16_t* dqkv, float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, AttnTune tune,
              const float* rope_cs, const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st) {
   if ((head_dim != 64 && head_dim != 128) || nH % nKV || !plan) return -1;
   tune = clamp_tune(tune, head_dim);
   AttnArgs a{};
   a.qkv = qkv; a.o = const_cast<bf16_t*>(o); a.d_o = d_o; a.dqkv = dqkv;
-  a.lse2 = const_cast<float*>(lse2); a.ndsum = ndsum; a.dkv_part = dkv_part;
+  a.lse2 = const_cast<float*>(lse2); a.ndsum = ndsum; a.nlse = nlse; a.dkv_part = dkv_part;
   a.seg_start = seg_start; a.seg_end = seg_end;
   a.rope_cs = rope_cs; a.rope_sn = rope_sn;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);

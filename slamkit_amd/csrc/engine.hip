@@ -105,6 +105,7 @@ struct SlamEngine {
   std::vector<hipEvent_t> pw_ev;   // timing pairs around the waits (exposed all-gather time), reused step after step
   size_t pw_used = 0;
   bool params_t_dirty = false;     // ranged optimizer updates leave the transposed weight images stale until backward needs them
+  float* nlse = nullptr;
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -189,6 +190,7 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->dqkv = c.take<bf16_t>(M * e->QKV);
   e->d_o = c.take<bf16_t>(M * d.n_heads * d.head_dim);
   e->dsum = c.take<float>(M * d.n_heads);
+  e->nlse = c.take<float>(M * d.n_heads);
   e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_kv_heads, d.head_dim) / sizeof(float));
   e->cosb = c.take<float>(M * (d.head_dim / 2));
   e->sinb = c.take<float>(M * (d.head_dim / 2));
@@ -652,7 +654,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     CK(mark(l, 5));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
     CK(fork(l, 3));
@@ -973,18 +975,19 @@ int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_s
 }
 size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim) {
   // the ABI call has no KV-head count: sized for nKV = nH (plain multi-head attention), the largest case
-  return attn_bwd_workspace_bytes(M, nH, head_dim) + (size_t)M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
+  return attn_bwd_workspace_bytes(M, nH, head_dim) + (size_t)2 * M * nH * sizeof(float) + attn_plan_ints(M) * sizeof(int) + 64;
 }
 int slam_op_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* ws,
                      const int32_t* seg_start, const int32_t* seg_end, int M, int nH, int nKV, int head_dim,
                      slam_stream_t s) {
   float* ndsum = ws;
-  float* part = ws + (size_t)M * nH;
+  float* nlse = ws + (size_t)M * nH;
+  float* part = ws + (size_t)2 * M * nH;
   int* plan = reinterpret_cast<int*>(part + attn_bwd_workspace_bytes(M, nH, head_dim) / sizeof(float));
   const AttnTune tune = attn_default_tune();
   int r = attn_plan(seg_start, seg_end, M, head_dim, tune, plan, (hipStream_t)s);
   if (r) return r;
-  return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, ndsum, (bf16_t*)dqkv, part, seg_start,
+  return attn_bwd((const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse2, ndsum, nlse, (bf16_t*)dqkv, part, seg_start,
                   seg_end, plan, tune, nullptr, nullptr, M, nH, nKV, head_dim, (hipStream_t)s);
 }
 int slam_op_cross_entropy(const void* logits, const int64_t* labels, double num_items, void* dlogits, float* row_loss,

@@ -59,7 +59,8 @@ size_t attn_bwd_workspace_bytes(int M, int nKV, int head_dim);
 // rope_cs / rope_sn (nullable): fp32 [M][head_dim/2] tables; when given, dq and dk are written already
 // rotated back (transpose rotation), i.e. as gradients of the pre-RoPE projections. plan (required) must come from
 // attn_plan with the same tune.
-int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* ndsum, bf16_t* dqkv,
+// ndsum, nlse: fp32 [nH * M] scratch each (-rowsum(dO*O) and -lse2, written by the dQ kernel for the dK/dV kernel)
+int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse2, float* ndsum, float* nlse, bf16_t* dqkv,
              float* dkv_part, const int* seg_start, const int* seg_end, const int* plan, AttnTune tune,
              const float* rope_cs, const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st);
 
