@@ -79,6 +79,7 @@ struct SlamEngine {
   // (down-proj dgrad with the fused SwiGLU backward) leaves the MFMA pipes free. Event pairs order every wgrad after the
   // kernel that produces its operands and every buffer re-use on the main stream after the wgrad that reads it.
   AttnTune attn_tune = attn_default_tune();
+  GemmTune gemm_tune = *gemm_default_tune();
   int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
   hipStream_t wside = nullptr;
   // "bwd_wgrad_cus" > 0: the wgrad stream is created with a CU mask of that many CUs (the low bits of the mask: on gfx950
@@ -441,6 +442,7 @@ int slam_bind_params_t(SlamEngine* h, void* params_t_bf16) {
 }
 size_t slam_workspace_bytes(SlamEngine* h, int64_t max_tokens) {
   if (!h || max_tokens <= 0) return 0;
+  GemmTuneScope tune_scope(&h->gemm_tune);
   SlamEngine tmp;
   tmp.d = h->d;
   tmp.QKV = h->QKV;
@@ -462,24 +464,10 @@ int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_token
 }
 int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!key) return SLAM_EINVAL;
-  if (!strcmp(key, "gemm_glds")) { gemm_set_glds((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn_dma")) { gemm_set_tn_dma((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_group_rows")) { gemm_set_group_rows((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn_splits")) { gemm_set_tn_splits((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_nt_store")) { gemm_set_nt_store((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256_persist")) { gemm_set_256_persist((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256")) { gemm_set_256((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_nt224")) { gemm_set_nt224((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_nt224_min_k")) { gemm_set_nt224_min_k((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_256_dswiglu")) { gemm_set_256_dswiglu((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_group_rows_256")) { gemm_set_group_rows_256((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn_balanced")) { gemm_set_tn_balanced((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn224")) { gemm_set_tn224((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn224_min_m")) { gemm_set_tn224_min_m((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn224_max_split")) { gemm_set_tn224_max_split((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn_bal_bg_max_split")) { gemm_set_tn_bal_bg_max_split((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn224_bg_min_m")) { gemm_set_tn224_bg_min_m((int)value); return SLAM_OK; }
-  if (!strcmp(key, "gemm_tn224_bg_max_split")) { gemm_set_tn224_bg_max_split((int)value); return SLAM_OK; }
+  if (!strncmp(key, "gemm_", 5)) {  // kernel-selection knobs: this engine's (h) or the process default's (h = NULL)
+    if (gemm_tune_set(h ? &h->gemm_tune : gemm_default_tune(), key, (long)value)) return SLAM_OK;
+    return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
+  }
   if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch") || !strcmp(key, "attn_prio")) {
     // with an engine: that engine's launches (takes effect at its next forward, which rebuilds the attention plan);
     // without: the process default picked up by the single-op entry points and by engines created afterwards
@@ -513,6 +501,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
   const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
   const bf16_t* P = h->params;
   h->have_fwd = false;
+  GemmTuneScope tune_scope(&h->gemm_tune);
 
   if (seg_start) {
     h->cur_seg_s = seg_start;
@@ -605,10 +594,12 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // k 0..3 main->side "operands ready" (wd, wgu, wo, wqkv), k 4..6 side->main "done reading" (dh, dh2, dqkv)
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
+  GemmTuneScope tune_scope(&h->gemm_tune);
   struct SharedGuard {  // dgrad launches of this call may plan for a GPU they share with the wgrad stream
-    explicit SharedGuard(int on) { gemm_set_shared(on); }
-    ~SharedGuard() { gemm_set_shared(0); }
-  } shared_guard(two ? 1 : 0);
+    GemmTune* t;
+    SharedGuard(GemmTune* t_, int on) : t(t_) { t->shared = on; }
+    ~SharedGuard() { t->shared = 0; }
+  } shared_guard(&h->gemm_tune, two ? 1 : 0);
   hipStream_t ws = two ? h->wside : st;
   auto ev = [&](int layer, int k) { return h->ev_w[(size_t)layer * 8 + k]; };
   auto fork = [&](int layer, int k) -> int {  // side stream continues after everything enqueued on main so far
@@ -910,11 +901,10 @@ int slam_cast_params(SlamEngine* h, const float* master, slam_stream_t stream) {
 // ---- single-op entry points ------------------------------------------------------------------
 int slam_op_gemm_nt(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
                     int use_glds, slam_stream_t s) {
-  gemm_set_glds(use_glds != 0);
-  int r = gemm_nt((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (const bf16_t*)bias, (const bf16_t*)resid, M, N, K,
-                  (hipStream_t)s);
-  gemm_set_glds(1);
-  return r;
+  GemmTune t = *gemm_default_tune();  // the process default with the staging mode of this call
+  t.glds = use_glds != 0;
+  GemmTuneScope scope(&t);
+  return gemm_nt((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (const bf16_t*)bias, (const bf16_t*)resid, M, N, K, (hipStream_t)s);
 }
 int slam_op_gemm_nt_swiglu(const void* X, const void* W, void* Y, void* act, int M, int N, int K, slam_stream_t s) {
   return gemm_nt_swiglu((const bf16_t*)X, (const bf16_t*)W, (bf16_t*)Y, (bf16_t*)act, M, N, K, (hipStream_t)s);

@@ -28,8 +28,39 @@
 // re-keyed swizzle) were removed in round 2; DESIGN.md section 4 keeps what each one measured.
 #include <type_traits>
 
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
+
+namespace slam {
+// ---- tuning state: one GemmTune per engine (kernels.h). The dispatch functions below read the CURRENT one, which an
+// engine entry point installs for the duration of its call (GemmTuneScope in engine.hip); outside any engine call - the
+// single-op entry points - the process default is current. Two engines in one process (DPO: policy + reference) no longer
+// share or toggle each other's settings.
+static GemmTune g_default_tune;
+static thread_local GemmTune* t_cur_tune = nullptr;
+GemmTune* gemm_default_tune() { return &g_default_tune; }
+GemmTune* gemm_use_tune(GemmTune* t) { GemmTune* old = t_cur_tune; t_cur_tune = t; return old; }
+GemmTune& T() { return t_cur_tune ? *t_cur_tune : g_default_tune; }
+int gemm_tune_set(GemmTune* t, const char* key, long v) {
+  auto clamp = [](long x, long lo, long hi) { return (int)(x < lo ? lo : x > hi ? hi : x); };
+  struct { const char* k; int* f; long lo, hi; } tab[] = {
+      {"gemm_glds", &t->glds, 0, 1}, {"gemm_tn_dma", &t->tn_dma, 0, 1}, {"gemm_group_rows", &t->group_rows, 1, 64},
+      {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, 1},
+      {"gemm_256_persist", &t->g256_persist, 0, 1}, {"gemm_256", &t->g256, 0, 2}, {"gemm_nt224", &t->nt224, 0, 2},
+      {"gemm_nt224_min_k", &t->nt224_min_k, 0, 1 << 30}, {"gemm_256_dswiglu", &t->g256_dswiglu, 0, 1},
+      {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
+      {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
+      {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
+      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}};
+  for (auto& e : tab)
+    if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
+  return 0;
+}
+
+}  // namespace slam
+using slam::T;
 
 namespace {
 
@@ -1444,8 +1475,8 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   *reinterpret_cast<float4*>(out + i) = s;
 }
 
-static int g_nt_store = 0;
-static int g_group_rows = 3;  // step-level A/B on MI355X (same box): 1 -> 32.4 ms, 2 -> 31.2, 3 -> 31.2, 4 -> 31.5, 8 -> 32.8
+// nt_store  (field of GemmTune, kernels.h)
+// group_rows: step-level A/B on MI355X (same box): 1 -> 32.4 ms, 2 -> 31.2, 3 -> 31.2, 4 -> 31.5, 8 -> 32.8  (field of GemmTune, kernels.h)
 
 template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false>
 int launch(GemmArgs a, int splits, hipStream_t st) {
@@ -1458,8 +1489,8 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
     attr_set = true;
   }
   a.tiles_r = (a.R + BM - 1) / BM;
-  a.group_rows = g_group_rows;
-  a.nt_store = g_nt_store;
+  a.group_rows = T().group_rows;
+  a.nt_store = T().nt_store;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
   gemm_kernel<TA, TB, F32OUT, GLDS, PERM><<<grid, 256, lds, st>>>(a);
   return (int)hipGetLastError();
@@ -1470,32 +1501,28 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
 namespace slam {
 
 // gemm_glds: 1 = LDS-DMA staging where the shape allows (default), 0 = register staging everywhere (parity tests)
-static int g_gemm_glds = 1;
+// gemm_glds  (field of GemmTune, kernels.h)
 // gemm_256: 1 = the 256 x 256 kernel when its fill criterion holds (default), 0 = never, 2 = whenever the shape allows (tests)
-static int g_gemm_256 = 1;
-void gemm_set_256(int on) { g_gemm_256 = on; }
+// gemm_256  (field of GemmTune, kernels.h)
 // the 256 x 256 kernel runs one block per CU: worth it when the tiles fill most of whole rounds of the 256 CUs
 // (gate|up forward: 1216 tiles = 4.75 rounds, 95 %; down-proj dgrad: 608 tiles = 2.4 rounds, 79 %: equal as a plain
 // GEMM, +1 % step throughput with its fused SwiGLU-backward epilogue; N = 1536 at M = 16384: 384 tiles = 1.5 rounds,
 // 75 %, still +4.7 % on the Qwen2.5-1.5B-shaped step because its contractions are long)
 static bool use_256(const GemmArgs& a) {
-  if (!g_gemm_256 || (a.R % 256) || (a.Cn % 256) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
+  if (!T().g256 || (a.R % 256) || (a.Cn % 256) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
   const int tiles = (a.R / 256) * (a.Cn / 256);
-  if (g_gemm_256 == 2) return tiles >= 256;  // forced (tests / A-B)
+  if (T().g256 == 2) return tiles >= 256;  // forced (tests / A-B)
   return tiles >= 256 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.74;
 }
 // the down-proj dgrad with the fused SwiGLU backward on the 256 x 256 kernel (1) or on the 128 x 128 kernel (0: two blocks
 // per CU, so that one block's HBM-bound epilogue sits beside another block's - or a concurrent wgrad's - MFMA loop)
-static int g_gemm_256_dswiglu = 1;
-void gemm_set_256_dswiglu(int on) { g_gemm_256_dswiglu = on; }
-static int g_group_rows_256 = 4;  // 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)
-void gemm_set_group_rows_256(int g) { g_group_rows_256 = g; }
+// gemm_256_dswiglu  (field of GemmTune, kernels.h)
+// group_rows_256: 256-row tile groups: 1 -> 145 us, 2 -> 135, 4 -> 133, 8 -> 133 (gate|up forward, plain)  (field of GemmTune, kernels.h)
 // persistent blocks (one per CU) walking the tile list with the DMA stream running across tile boundaries: 0 = one
 // block per tile, 1 = whenever there are more tiles than CUs and the epilogue has no bias / residual / RoPE operand.
 // Same box, interleaved: gate|up forward + SwiGLU 147.4 -> 136.3 us, plain 130.0 -> 121.5, down-proj dgrad + dSwiGLU
 // 109.1 -> 104.7, LM head of the 152k vocabulary 6294 -> 6106; Slam-358M step 313.4 k -> 319.7 k tok/s (two pairs)
-static int g_gemm_256_persist = 1;
-void gemm_set_256_persist(int on) { g_gemm_256_persist = on; }
+// gemm_256_persist  (field of GemmTune, kernels.h)
 static int launch_256(GemmArgs a, hipStream_t st) {
   static int cus = 0;
   if (!cus) {
@@ -1508,26 +1535,23 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   }
   a.tiles_r = a.R / 256;
   a.tiles_c = a.Cn / 256;
-  a.group_rows = g_group_rows_256;
-  a.nt_store = g_nt_store;
+  a.group_rows = T().group_rows_256;
+  a.nt_store = T().nt_store;
   const int tiles = a.tiles_r * a.tiles_c;
-  if (g_gemm_256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
+  if (T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
   else gemm_nt_256_kernel<false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
 
 // 256 x 224 NT kernel: only in "shared" mode (the engine's two-stream backward), plain or residual epilogue
-static int g_shared = 0;      // set by the engine around slam_backward when the wgrad stream is on
-static int g_nt224 = 1;       // 0 = off, 1 = in shared mode (default), 2 = whenever the shape allows (tests)
-static int g_nt224_min_k = 2048;  // long contractions only (gate|up dgrad, K = 9728): interleaved A/B x3 on the Slam-358M step 311.5-312.0k vs 310.3-310.6k tok/s; with the K = 896 / 1152 dgrads as well: no gain
-void gemm_set_shared(int on) { g_shared = on; }
-void gemm_set_nt224(int v) { g_nt224 = v; }
-void gemm_set_nt224_min_k(int v) { g_nt224_min_k = v; }
+// shared: set by the engine around slam_backward when the wgrad stream is on  (field of GemmTune, kernels.h)
+// nt224: 0 = off, 1 = in shared mode (default), 2 = whenever the shape allows (tests)  (field of GemmTune, kernels.h)
+// nt224_min_k: long contractions only (gate|up dgrad, K = 9728): interleaved A/B x3 on the Slam-358M step 311.5-312.0k vs 310.3-310.6k tok/s; with the K = 896 / 1152 dgrads as well: no gain  (field of GemmTune, kernels.h)
 static bool use_nt224(const GemmArgs& a) {
-  if (!g_nt224 || (a.R % 256) || (a.Cn % 224) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
+  if (!T().nt224 || (a.R % 256) || (a.Cn % 224) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
   if (a.bias || a.act || a.gu || a.rope_cos) return false;
-  if (g_nt224 == 2) return true;
-  return g_shared && a.Kc >= g_nt224_min_k && (a.R / 256) * (a.Cn / 224) >= 64;
+  if (T().nt224 == 2) return true;
+  return T().shared && a.Kc >= T().nt224_min_k && (a.R / 256) * (a.Cn / 224) >= 64;
 }
 static int launch_nt224(GemmArgs a, hipStream_t st) {
   static bool attr = false;
@@ -1547,11 +1571,7 @@ static int launch_nt_dma(const GemmArgs& a, hipStream_t st) {
   if (use_256(a)) return launch_256(a, st);
   return launch<false, false, false, true, true>(a, 1, st);
 }
-static int g_gemm_tn_dma = 1;
-void gemm_set_glds(int mode) { g_gemm_glds = mode; }
-void gemm_set_tn_dma(int on) { g_gemm_tn_dma = on; }
-void gemm_set_group_rows(int g) { g_group_rows = g; }
-void gemm_set_nt_store(int on) { g_nt_store = on; }
+// gemm_tn_dma  (field of GemmTune, kernels.h)
 
 static int check_dims(int R, int Cn, int Kc, int lda, int ldb, int ldc) {
   if (R <= 0 || Cn <= 0 || Kc <= 0) return -1;
@@ -1566,7 +1586,7 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
   GemmArgs a{X, W, Y, bias, resid, nullptr, nullptr, M, N, K, K, K, N, ((K + BK - 1) / BK) * BK, (M + BM - 1) / BM,
              (N + BN - 1) / BN};
   const bool dma_ok = (K % BK == 0) && (N % BN == 0);
-  if (dma_ok && g_gemm_glds) return launch_nt_dma(a, st);
+  if (dma_ok && T().glds) return launch_nt_dma(a, st);
   return launch<false, false, false, false>(a, 1, st);
 }
 
@@ -1589,7 +1609,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
   GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  if (!g_gemm_256_dswiglu) return launch<false, false, false, true, true>(a, 1, st);
+  if (!T().g256_dswiglu) return launch<false, false, false, true, true>(a, 1, st);
   return launch_nt_dma(a, st);
 }
 
@@ -1602,10 +1622,9 @@ int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, 
   return launch<false, true, false, false>(a, 1, st);
 }
 
-static int g_tn_splits_override = 0;
-void gemm_set_tn_splits(int s) { g_tn_splits_override = s; }
+// tn_splits_override  (field of GemmTune, kernels.h)
 int gemm_tn_splits(int M, int N, int K) {
-  if (g_tn_splits_override > 0) return g_tn_splits_override;
+  if (T().tn_splits_override > 0) return T().tn_splits_override;
   int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
   // measured on MI355X (tools/gemm_bench.py split sweep): ~380 blocks for the few-tile weights
   // (wqkv 63 tiles -> 6, wo 49 -> 8), ~800 for the big ones (wd 266 -> 3, wgu 532 -> 2)
@@ -1617,15 +1636,13 @@ int gemm_tn_splits(int M, int N, int K) {
   return s;
 }
 // balanced plan for the DMA-eligible shapes (see gemm_tn_bal_kernel)
-static int g_tn_balanced = 1;
-void gemm_set_tn_balanced(int on) { g_tn_balanced = on; }
+// tn_balanced  (field of GemmTune, kernels.h)
 static const int BAL_SLOTS = 512;  // 2 blocks per CU on the 256-CU MI355X
 struct BalPlan { int T_A, S_A, per_A, SA_act, T_B, S_B, per_B, SB_act; };
 static bool tn_bal_ok(int M, int N, int K) {
-  return g_tn_balanced && g_gemm_tn_dma == 1 && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
+  return T().tn_balanced && T().tn_dma == 1 && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
 }
-static int g_bal_bg_max_split = 4;  // background launches of the 128 x 128 balanced kernel: limit on pieces per tile (measured on the Slam-358M step: 1 -> 291.7k, 2 -> 306.4k, 3 -> 312.2k, 4 -> 312.4k, 5 -> 311.3k, 6 -> 310.6k, 8 -> 308.7k tok/s)
-void gemm_set_tn_bal_bg_max_split(int v) { g_bal_bg_max_split = v < 1 ? 1 : v > 8 ? 8 : v; }
+// bal_bg_max_split: background launches of the 128 x 128 balanced kernel: limit on pieces per tile (measured on the Slam-358M step: 1 -> 291.7k, 2 -> 306.4k, 3 -> 312.2k, 4 -> 312.4k, 5 -> 311.3k, 6 -> 310.6k, 8 -> 308.7k tok/s)  (field of GemmTune, kernels.h)
 static BalPlan tn_bal_plan(int M, int N, int K, int max_split = 8) {
   const int T = (N / BM) * (K / BN), KS = M / BK;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
@@ -1663,23 +1680,18 @@ static BalPlan tn_bal_plan(int M, int N, int K, int max_split = 8) {
 
 // ---- 256 x 224 phase-scheduled wgrad: shape test, balanced plan, launch -------------------------------------------------
 // tn224: 0 = off, 1 = when the plan fills the chip (default), 2 = whenever the shape allows (tests)
-static int g_tn224 = 1;
-static int g_tn224_min_m = 16384, g_tn224_max_split = 16;
+// tn224  (field of GemmTune, kernels.h)
+// tn224_min_m, tn224_max_split  (field of GemmTune, kernels.h)
 // "background" launches (the engine's wgrad side stream: other kernels fill whatever CUs a launch leaves free, so what
 // counts is CU-time per flop, not chip fill): no K-splitting at all - one block per tile walks the whole contraction (no
 // slabs, no reduce pass, 128 K-steps of main loop per 229 KB epilogue), from much shorter contractions on.
 // Measured on the Slam-358M step (same box, twice): 304.6k tok/s vs 292.5k with the balanced 128 x 128 kernel on that
 // stream (+4.1 %); limits of 2 / 3 / 16 pieces: 299.0k / 288.1k / 289.4k.
-static int g_tn224_bg_min_m = 4096, g_tn224_bg_max_split = 1;
-void gemm_set_tn224(int v) { g_tn224 = v; }
-void gemm_set_tn224_min_m(int v) { g_tn224_min_m = v; }
-void gemm_set_tn224_max_split(int v) { g_tn224_max_split = v < 1 ? 1 : v > 16 ? 16 : v; }
-void gemm_set_tn224_bg_min_m(int v) { g_tn224_bg_min_m = v; }
-void gemm_set_tn224_bg_max_split(int v) { g_tn224_bg_max_split = v < 1 ? 1 : v > 16 ? 16 : v; }
+// tn224_bg_min_m, tn224_bg_max_split  (field of GemmTune, kernels.h)
 struct Plan224 { int T_A, S_A, per_A, T_B, S_B, per_B, slabs; bool tr; int tiles_a, tiles_b; };
 // orientation: 0 = none, 1 = dW[n][k] with n on the 256 side (N % 256 == 0, K % 224 == 0), 2 = transposed store (k on the 256 side)
 static int tn224_orient(int M, int N, int K, int background = 0) {
-  if (!g_tn224 || (M % BK)) return 0;
+  if (!T().tn224 || (M % BK)) return 0;
   const bool o1 = (N % 256 == 0) && (K % 224 == 0), o2 = (K % 256 == 0) && (N % 224 == 0);
   if (!o1 && !o2) return 0;
   const long tiles = (long)N * K / (256 * 224);
@@ -1687,12 +1699,12 @@ static int tn224_orient(int M, int N, int K, int background = 0) {
   // contraction, but at M = 8192 every piece is 13..64 K-steps long and the one-block-per-CU epilogue (229 KB of fp32 per
   // piece, nothing to overlap it with) plus the slab pass give the gain back: gate|up weight 148-157 us vs 149-153,
   // down weight 77 vs 86 us, Slam-358M step 291.1k vs 294.3k tok/s. Default: contractions of 16,384 tokens and more.
-  if (g_tn224 != 2 && (background ? (tiles < 32 || M < g_tn224_bg_min_m) : (tiles < 64 || M < g_tn224_min_m))) return 0;
+  if (T().tn224 != 2 && (background ? (tiles < 32 || M < T().tn224_bg_min_m) : (tiles < 64 || M < T().tn224_min_m))) return 0;
   return o1 ? 1 : 2;
 }
 static Plan224 tn224_plan(int M, int N, int K, int orient, int max_split = -1) {
   Plan224 best{};
-  if (max_split < 1) max_split = g_tn224_max_split;
+  if (max_split < 1) max_split = T().tn224_max_split;
   const int SLOTS = 256;  // one block per CU
   const int T = (N / (orient == 1 ? 256 : 224)) * (K / (orient == 1 ? 224 : 256)), KS = M / BK;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
@@ -1749,7 +1761,7 @@ static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumu
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const Plan224 pl = tn224_plan(M, N, K, orient, background ? g_tn224_bg_max_split : g_tn224_max_split);
+  const Plan224 pl = tn224_plan(M, N, K, orient, background ? T().tn224_bg_max_split : T().tn224_max_split);
   Tn224Args a{};
   a.A = orient == 1 ? dY : X; a.lda = orient == 1 ? ldy : ldx;
   a.B = orient == 1 ? X : dY; a.ldb = orient == 1 ? ldx : ldy;
@@ -1796,7 +1808,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
             int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
   if (const int orient = tn224_orient(M, N, K, background)) {
-    const Plan224 pl = tn224_plan(M, N, K, orient, background ? g_tn224_bg_max_split : g_tn224_max_split);
+    const Plan224 pl = tn224_plan(M, N, K, orient, background ? T().tn224_bg_max_split : T().tn224_max_split);
     if ((size_t)pl.slabs * 256 * 224 * sizeof(float) > ws_bytes) return -3;
     return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st);
   }
@@ -1808,11 +1820,11 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
       if (e != hipSuccess) return (int)e;
       attr = true;
     }
-    const BalPlan pl = tn_bal_plan(M, N, K, background ? g_bal_bg_max_split : 8);
+    const BalPlan pl = tn_bal_plan(M, N, K, background ? T().bal_bg_max_split : 8);
     if (bal_plan_bytes(pl, N, K) > ws_bytes) return -3;
     BalArgs a{};
     a.A = dY; a.B = X; a.dW = dW; a.lda = ldy; a.ldb = ldx; a.ldc = K;
-    a.tiles_r = N / BM; a.tiles_c = K / BN; a.KS = M / BK; a.group_rows = g_group_rows;
+    a.tiles_r = N / BM; a.tiles_c = K / BN; a.KS = M / BK; a.group_rows = T().group_rows;
     a.T_A = pl.T_A; a.S_A = pl.S_A; a.per_A = pl.per_A; a.T_B = pl.T_B; a.S_B = pl.S_B; a.per_B = pl.per_B;
     a.nA = pl.T_A * pl.SA_act;
     a.accumulate = accumulate;
@@ -1830,7 +1842,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   splits = (M + per - 1) / per;
   if ((size_t)splits * N * K * sizeof(float) > ws_bytes) return -3;
   GemmArgs a{dY, X, ws, nullptr, nullptr, nullptr, nullptr, N, K, M, ldy, ldx, K, per, (N + BM - 1) / BM, (K + BN - 1) / BN};
-  const bool dma_ok = g_gemm_tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
+  const bool dma_ok = T().tn_dma && (N % BM == 0) && (K % BN == 0) && (M % BK == 0);
   int e = dma_ok ? launch<true, true, true, true>(a, splits, st) : launch<true, true, true, false>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;

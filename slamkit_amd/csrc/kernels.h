@@ -9,25 +9,28 @@ typedef uint16_t bf16_t;
 namespace slam {
 
 // gemm.hip
-void gemm_set_glds(int on);
-void gemm_set_tn_dma(int on);
-void gemm_set_tn_splits(int s);
-void gemm_set_group_rows(int g);
-void gemm_set_nt_store(int on);
-void gemm_set_256_persist(int on);
-void gemm_set_256(int on);
-void gemm_set_shared(int on);
-void gemm_set_nt224(int v);
-void gemm_set_nt224_min_k(int v);
-void gemm_set_256_dswiglu(int on);
-void gemm_set_group_rows_256(int g);
-void gemm_set_tn_balanced(int on);
-void gemm_set_tn224(int v);
-void gemm_set_tn224_min_m(int v);
-void gemm_set_tn224_max_split(int v);
-void gemm_set_tn_bal_bg_max_split(int v);
-void gemm_set_tn224_bg_min_m(int v);
-void gemm_set_tn224_bg_max_split(int v);
+// Kernel-selection / planning knobs of the GEMM dispatch (DESIGN.md section 4 has the measurement behind each default). One
+// instance per engine; an engine entry point makes its instance current for the duration of the call (GemmTuneScope).
+struct GemmTune {
+  int glds = 1;                 // 1 = LDS-DMA staging where the shape allows, 0 = register staging everywhere (parity tests)
+  int tn_dma = 1;
+  int group_rows = 3, group_rows_256 = 4;   // row-tile groups of the L2-aware block order (128 / 256-row tiles)
+  int nt_store = 0;
+  int g256 = 1;                 // 256 x 256 NT kernel: 1 = when its fill criterion holds, 0 = never, 2 = whenever the shape allows
+  int g256_dswiglu = 1, g256_persist = 1;
+  int shared = 0;               // the launches of this call share the GPU with the engine's wgrad stream (set inside slam_backward)
+  int nt224 = 1, nt224_min_k = 2048;
+  int tn_splits_override = 0, tn_balanced = 1, bal_bg_max_split = 4;
+  int tn224 = 1, tn224_min_m = 16384, tn224_max_split = 16, tn224_bg_min_m = 4096, tn224_bg_max_split = 1;
+};
+GemmTune* gemm_default_tune();
+GemmTune* gemm_use_tune(GemmTune* t);  // install t (NULL = process default) for this thread; returns the previous one
+int gemm_tune_set(GemmTune* t, const char* key, long value);  // "gemm_*" option keys of slam_set_option; 1 = key known
+struct GemmTuneScope {
+  GemmTune* old;
+  explicit GemmTuneScope(GemmTune* t) : old(gemm_use_tune(t)) {}
+  ~GemmTuneScope() { gemm_use_tune(old); }
+};
 int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const bf16_t* resid, int M, int N,
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
