@@ -121,16 +121,6 @@ struct FragOff {
 };
 struct TileAddr {
   uint32_t d[2], t[4];
-  int soff = 0;  // compile-time stage offset when the ring is unrolled (set_static): folded into the read immediates
-  // ring unrolled by its depth: the fragment offsets already carry the LDS base, the stage is an immediate - no per-tile
-  // address arithmetic and no second set of address registers
-  SLAM_DEVICE void set_static(const FragOff& fo, int stage_off) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) d[i] = fo.d[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = fo.t[i];
-    soff = stage_off;
-  }
   SLAM_DEVICE void set(const FragOff& fo, uint32_t stage_base) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) { d[i] = stage_base + fo.d[i]; asm volatile("" : "+v"(d[i])); }
@@ -139,13 +129,13 @@ struct TileAddr {
   }
   // a-operand from image `img` (byte offset inside the stage): rows 16f.., head_dim block g + 4ds (contraction along head_dim)
   SLAM_DEVICE uint4 D(int img, int f, int ds) const {
-    const u32x4_t v = *(lds_u4ptr_t)(lds_p(d[ds]) + (soff + img + f * 2048));
+    const u32x4_t v = *(lds_u4ptr_t)(lds_p(d[ds]) + (img + f * 2048));
     return make_uint4(v[0], v[1], v[2], v[3]);
   }
   // a-operand for contraction step t2 (rows 32 t2 .. +31 of the tile), output column block fd (contraction along the rows):
   // rows {32t + 4g + r} U {32t + 16 + 4g + r}, r = 0..3 - the order the P / dS b-operand is packed in
   SLAM_DEVICE uint4 T(int img, int fd, int t2) const {
-    lds_cptr_t q = lds_p(t[fd]) + (soff + img + t2 * 4096);
+    lds_cptr_t q = lds_p(t[fd]) + (img + t2 * 4096);
     typedef __attribute__((address_space(3))) s16x4_t* trp_t;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)q);
     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(q + 2048));
@@ -201,26 +191,17 @@ inline int item_grid(int ntile, int nH, int nKV) { return ((ntile * nKV + 7) / 8
 // ------------------------------------------------------------------------------------------
 // Forward. wave w owns query rows q0+32w .. +31 (two 16-row fragments) of a 128-row tile.
 // Stage = K image + V image (16 KB per 64 head-dim columns), 3-stage ring at head_dim 64 / 2-stage at 128.
-// NG = wave groups per block ("attn_ng"): with NG = 2 a block is 8 waves - two groups of four that own the SAME 128 query
-// rows and take alternate key tiles, each through its own DMA ring; at the end group 1 hands its (O, l, m) to group 0
-// through LDS. At 1024-token sequences the longest block walks 16 key tiles while three blocks share a CU: that serial
-// chain, not the chip's throughput, sets the kernel's time (measured: 30 us against 11 us of SIMD work per CU); two groups
-// halve the chain and put four waves on a SIMD.
-template <int ND, int NG>
+template <int ND>
 struct FwdCfg {
-  static constexpr int NST = (ND == 1 && NG == 1) ? 3 : 2;   // ring depth per group
+  static constexpr int NST = ND == 1 ? 3 : 2;   // ring depth: 48 KB (3 blocks/CU) or 64 KB (2 blocks/CU)
   static constexpr int STAGE = 2 * ND * IMG;
-  static constexpr int LDS = NG * NST * STAGE;               // 48 KB (3 blocks/CU), 64 KB (2 blocks/CU)
-  static constexpr int OCC = ND == 1 ? (NG == 1 ? 3 : 4) : 2;  // waves per SIMD the register budget is cut for
-  static constexpr bool PREFETCH = !(ND == 1 && NG == 2);     // V fragments ahead of the exp arithmetic (+32 registers)
+  static constexpr int OCC = ND == 1 ? 3 : 2;
 };
-template <int ND, int NG>
-__global__ __launch_bounds__(256 * NG, (FwdCfg<ND, NG>::OCC)) void attn_fwd_kernel(AttnArgs p) {
-  constexpr int NST = FwdCfg<ND, NG>::NST, STG = FwdCfg<ND, NG>::STAGE, D = 64 * ND;
-  constexpr bool PF = FwdCfg<ND, NG>::PREFETCH;
+template <int ND>
+__global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int NST = FwdCfg<ND>::NST, STG = FwdCfg<ND>::STAGE, D = 64 * ND;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);  // wave group
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // position inside the group
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.M, ld = p.ldq;
   const BlockItem bi = block_item(blockIdx.x, (M + 127) / 128, p.nH, p.nKV);
@@ -233,31 +214,21 @@ __global__ __launch_bounds__(256 * NG, (FwdCfg<ND, NG>::OCC)) void attn_fwd_kern
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
   const float c2 = p.scale * 1.44269504088896340736f;
-  const int gu = __builtin_amdgcn_readfirstlane(grp);
-  const uint32_t lds0 = lds_addr(smem) + (uint32_t)(gu * (NST * STG));  // this group's ring
+  const uint32_t lds0 = lds_addr(smem);
 
   const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
   const int kt_end = (min(q0 + 127, M - 1)) / 64;
-  const int n_all = kt_end - kt_begin + 1;
-  const int n = (n_all - gu + NG - 1) / NG;        // key tiles of this group: kt_begin + gu, + NG, ...
-  const int n_loop = (n_all + NG - 1) / NG;         // iterations of the block (every wave meets every barrier)
+  const int n = kt_end - kt_begin + 1;
   TileOff off;
   off.init(ld, tid);
-  constexpr bool STATIC_RING = NG == 2;  // ring unrolled by its depth (2): stage offsets are immediates
   FragOff fo;
   fo.init(l15, g);
-  if constexpr (STATIC_RING) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fo.d[i] += lds0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fo.t[i] += lds0;
-  }
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   // running tile pointers (wave-uniform): one 64-bit add per operand per tile
-  const size_t tstep = (size_t)64 * NG * ld;
-  const bf16_t* kp = Kb + (size_t)(kt_begin + gu) * 64 * ld;
-  const bf16_t* vp = Vb + (size_t)(kt_begin + gu) * 64 * ld;
-  int irow = (kt_begin + gu) * 64;
+  const size_t tstep = (size_t)64 * ld;
+  const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
+  const bf16_t* vp = Vb + (size_t)kt_begin * tstep;
+  int irow = kt_begin * 64;
   const uint32_t wdst = lds0 + (uint32_t)wv * 1024u;
   auto issue = [&](int stage) __attribute__((always_inline)) {
     const uint32_t st = wdst + (uint32_t)(stage * STG);
@@ -275,7 +246,7 @@ __global__ __launch_bounds__(256 * NG, (FwdCfg<ND, NG>::OCC)) void attn_fwd_kern
         dma_tile64<false>(vp + dh * 64, off, mr, st + (ND + dh) * IMG);
       }
     }
-    kp += tstep; vp += tstep; irow += 64 * NG;
+    kp += tstep; vp += tstep; irow += 64;
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -308,185 +279,118 @@ __global__ __launch_bounds__(256 * NG, (FwdCfg<ND, NG>::OCC)) void attn_fwd_kern
 #pragma unroll
     for (int fd = 0; fd < 4 * ND; ++fd) ot[fd][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
+  bool started[2] = {false, false};
   const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 x 8
   wait_all_loads_visible();
 
   int stage = 0, istage = (NST - 1) % NST;
-  auto iter = [&](int t, auto sc) __attribute__((always_inline)) {
-    constexpr int S = decltype(sc)::value;  // stage of tile t when the ring is unrolled, -1 = run-time stage counters
+  for (int t = 0; t < n; ++t) {
     // 3-deep ring: tile t landed once at most one later tile (4 DMAs per 64 head-dim columns) is in flight
     if (NST >= 3 && t + 1 < n) wait_vmcnt<4 * ND>();
     else wait_vmcnt<0>();
     __syncthreads();
-    if (t + NST - 1 < n) issue(S >= 0 ? (S + NST - 1) % NST : istage);
+    if (t + NST - 1 < n) issue(istage);
+    istage = istage + 1 == NST ? 0 : istage + 1;
+    const uint32_t sb = lds0 + (uint32_t)(stage * STG);
+    stage = stage + 1 == NST ? 0 : stage + 1;
+    const int key0 = (kt_begin + t) * 64;
+    if (key0 > qw0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
     TileAddr ta;
-    if constexpr (S >= 0) {
-      ta.set_static(fo, S * STG);
-    } else {
-      istage = istage + 1 == NST ? 0 : istage + 1;
-      ta.set(fo, lds0 + (uint32_t)(stage * STG));
-      stage = stage + 1 == NST ? 0 : stage + 1;
-    }
-    const int key0 = (kt_begin + gu + t * NG) * 64;
-    if (t >= n || key0 > qw0 + 31) return;  // wave-uniform: no tile left for this group / tile entirely above this wave's diagonal
-    // NH key halves per tile: with two wave groups (128 registers per wave) a tile is processed as two 32-key halves -
-    // scores, running-max test, exp, P.V of one half before the scores of the next - so that only 16 score registers and one
-    // packed P fragment per row block are live at a time
-    constexpr int NH = NG == 2 ? 2 : 1, FH = 4 / NH, TH = FH / 2;
-    const bool need_mask = (key0 + 63 > qw0) || (key0 < segmax_w);  // wave-uniform: diagonal or segment-boundary tile
+    ta.set(fo, sb);
+    f32x4_t st[4][2];
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      f32x4_t st[FH][2];
+    for (int ds = 0; ds < 2 * ND; ++ds)
 #pragma unroll
-      for (int ds = 0; ds < 2 * ND; ++ds)
+      for (int f = 0; f < 4; ++f) {
+        uint4 kf = ta.D((ds >> 1) * IMG, f, ds & 1);
 #pragma unroll
-        for (int f = 0; f < FH; ++f) {
-          uint4 kf = ta.D((ds >> 1) * IMG, hh * FH + f, ds & 1);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], ds == 0 ? negm[j] : st[f][j]);
-        }
-      if (need_mask) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int hi = qrow[j] - key0 - 4 * g, lo = segs[j] - key0 - 4 * g;  // key f*16 + 4g + r visible iff lo <= 16f + r <= hi
-#pragma unroll
-          for (int f = 0; f < FH; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const bool ok = ((hh * FH + f) * 16 + r <= hi) & ((hh * FH + f) * 16 + r >= lo);
-              st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
-            }
-        }
+        for (int j = 0; j < 2; ++j) st[f][j] = mfma16(kf, qf[j][ds], ds == 0 ? negm[j] : st[f][j]);
       }
-      // Deferred running max: the scores are already relative to m; m moves - with the cross-lane reduction, the exp of
-      // the correction, the rescale of O and l and the shift of these scores - only when a score exceeds it by more than
-      // 8 (P <= 256), or on the first keys the row sees at all (then m becomes the true row max: a row whose scores all sit
-      // far below zero must not underflow against m = 0; "started" = the row sum is positive, its largest term being 1).
-      // The test is lane-local and wave-uniform via a ballot: the common case has no shuffles and no dependent chain.
-      float mloc[2];
-      bool grow = false;
+    if ((key0 + 63 > qw0) || (key0 < segmax_w)) {  // wave-uniform: diagonal or segment-boundary tile
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float mx = NEG_BIG;
+        const int hi = qrow[j] - key0 - 4 * g, lo = segs[j] - key0 - 4 * g;  // key f*16 + 4g + r visible iff lo <= 16f + r <= hi
 #pragma unroll
-        for (int f = 0; f < FH; ++f)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
-        mloc[j] = mx;
-        grow |= (mx > 8.0f) | (!(lacc[j][0] > 0.f) & (mx > 0.5f * NEG_BIG));
-      }
-      if (__any(grow)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float mx = mloc[j];
-          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-          if (mx > 0.5f * NEG_BIG) {  // the row sees a key here (the same for the four lanes of a row)
-            const bool started = lacc[j][0] > 0.f;
-            const float shift = started ? -fmaxf(mx, 0.f) : -mx;  // m_old - m_new: m grows by max(mx, 0) once started; becomes the true max before
-            const float alpha = started ? fast_exp2(shift) : 1.f;  // (nothing accumulated before the first key: exp2(-mx) may be inf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { negm[j][r] += shift; lacc[j][r] *= alpha; }
-#pragma unroll
-            for (int fd = 0; fd < 4 * ND; ++fd)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
-#pragma unroll
-            for (int f = 0; f < FH; ++f)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) st[f][j][r] += shift;
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (f * 16 + r <= hi) & (f * 16 + r >= lo);
+            st[f][j][r] = ok ? st[f][j][r] : NEG_BIG;
           }
-        }
-      }
-      // the V^T fragments of the first contraction half are requested BEFORE the exp / pack arithmetic and land under it
-      // (left to itself the compiler sinks every fragment read to just before its MFMA pair: eight exposed LDS latencies)
-      uint4 vf0[4 * ND];
-      if constexpr (PF) {
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd) vf0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, hh * TH);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      uint4 pb[TH][2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int f = 0; f < FH; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[f][j][r] = fast_exp2(st[f][j][r]);  // masked entries (NEG_BIG) underflow to exactly 0
-#pragma unroll
-        for (int th = 0; th < TH; ++th) pb[th][j] = pack_pair(st[2 * th][j], st[2 * th + 1][j]);
-      }
-      if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int th = 0; th < TH; ++th) {
-        uint4 vf[4 * ND];
-        if constexpr (PF) {  // the next contraction half is requested before this half's MFMAs
-          if (th + 1 < TH) {
-#pragma unroll
-            for (int fd = 0; fd < 4 * ND; ++fd) vf[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, hh * TH + th + 1);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) lacc[j] = mfma16(ones, pb[th][j], lacc[j]);
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd) {
-          const uint4 v = PF ? vf0[fd] : ta.T((ND + (fd >> 2)) * IMG, fd & 3, hh * TH + th);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(v, pb[th][j], ot[fd][j]);
-        }
-        if constexpr (PF) {
-          if (th + 1 < TH) {
-#pragma unroll
-            for (int fd = 0; fd < 4 * ND; ++fd) vf0[fd] = vf[fd];
-          }
-        }
       }
     }
-  };
-  if constexpr (STATIC_RING) {
-    static_assert(!STATIC_RING || NST == 2, "the unrolled ring is two stages deep");
-    for (int t = 0; t < n_loop; t += 2) {
-      iter(t, std::integral_constant<int, 0>{});
-      if (t + 1 < n_loop) iter(t + 1, std::integral_constant<int, 1>{});
-    }
-  } else {
-    for (int t = 0; t < n_loop; ++t) iter(t, std::integral_constant<int, -1>{});
-  }
-  if constexpr (NG == 2) {
-    // hand-over: group 1 -> LDS -> group 0 (lane-linear rows of 256 B per register: conflict-free both ways). A group that
-    // saw no visible key for a row has l = 0 and contributes nothing.
-    constexpr int NV = 2 * (4 * ND * 4 + 2);  // floats per lane: O (both row fragments) + l + (-m)
-    __syncthreads();                           // every wave is done with the key / value tiles: the rings are free
-    float* xb = reinterpret_cast<float*>(smem) + (size_t)wave * (NV * 64) + lane;
-    if (grp == 1) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xb[((j * (4 * ND) + fd) * 4 + r) * 64] = ot[fd][j][r];
-        xb[(2 * 4 * ND * 4 + j) * 64] = lacc[j][0];
-        xb[(2 * 4 * ND * 4 + 2 + j) * 64] = negm[j][0];
-      }
-    }
-    __syncthreads();
-    if (grp == 1) return;
+    // Deferred running max: the scores are already relative to m; m moves - with the cross-lane reduction, the exp of the
+    // correction, the rescale of O and l and the shift of this tile's scores - only when a score exceeds it by more than
+    // 8 (P <= 256), or on the first tile in which the row sees a key at all (then m becomes the true row max: a row
+    // whose scores all sit far below zero must not underflow against m = 0). The test is lane-local and wave-uniform
+    // via a ballot, so the common tile has no shuffles and no dependent chain.
+    float mloc[2];
+    bool grow = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float l1 = xb[(2 * 4 * ND * 4 + j) * 64], nm1 = xb[(2 * 4 * ND * 4 + 2 + j) * 64];
-      const float l0 = lacc[j][0], nm0 = negm[j][0];
-      // m = max over the groups that have something; weights exp2(m_g - m) (0 for an empty group)
-      const float m0 = l0 > 0.f ? -nm0 : NEG_BIG, m1 = l1 > 0.f ? -nm1 : NEG_BIG;
-      const float mm = fmaxf(m0, m1);
-      const float a0 = l0 > 0.f ? fast_exp2(m0 - mm) : 0.f, a1 = l1 > 0.f ? fast_exp2(m1 - mm) : 0.f;
+      float mx = NEG_BIG;
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ot[fd][j][r] = ot[fd][j][r] * a0 + xb[((j * (4 * ND) + fd) * 4 + r) * 64] * a1;
-      const float l = l0 * a0 + l1 * a1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { lacc[j][r] = l; negm[j][r] = -mm; }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
+      mloc[j] = mx;
+      grow |= (mx > 8.0f) | (!started[j] & (mx > 0.5f * NEG_BIG));
     }
+    if (__any(grow)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float mx = mloc[j];
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx > 0.5f * NEG_BIG) {  // the row sees a key in this tile (the same for the four lanes of a row)
+          const float shift = started[j] ? -fmaxf(mx, 0.f) : -mx;  // m_old - m_new: m grows by max(mx, 0) once started; becomes the true max before
+          const float alpha = started[j] ? fast_exp2(shift) : 1.f;  // (nothing accumulated yet before the first key: exp2(-mx) may be inf)
+          started[j] = true;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { negm[j][r] += shift; lacc[j][r] *= alpha; }
+#pragma unroll
+          for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[fd][j][r] *= alpha;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[f][j][r] += shift;
+        }
+      }
+    }
+    // the V^T fragments of the first contraction half are requested BEFORE the exp / pack arithmetic and land under it
+    // (left to itself the compiler sinks every fragment read to just before its MFMA pair: eight exposed LDS latencies)
+    uint4 vf0[4 * ND];
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd) vf0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 pb[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[f][j][r] = fast_exp2(st[f][j][r]);  // masked entries (NEG_BIG) underflow to exactly 0
+      pb[0][j] = pack_pair(st[0][j], st[1][j]);
+      pb[1][j] = pack_pair(st[2][j], st[3][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 vf1[4 * ND];  // second half: requested before the first half's MFMAs
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd) vf1[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lacc[j] = mfma16(ones, pb[0][j], lacc[j]);
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf0[fd], pb[0][j], ot[fd][j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lacc[j] = mfma16(ones, pb[1][j], lacc[j]);
+#pragma unroll
+    for (int fd = 0; fd < 4 * ND; ++fd)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ot[fd][j] = mfma16(vf1[fd], pb[1][j], ot[fd][j]);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -509,22 +413,17 @@ __global__ __launch_bounds__(256 * NG, (FwdCfg<ND, NG>::OCC)) void attn_fwd_kern
 // ------------------------------------------------------------------------------------------
 // dQ. wave w owns query rows q0 + 16 JQ w .. of a 64 JQ-row tile (JQ 16-row fragments per wave).
 // Stage = K image (read both ways) + V image: 16 KB per 64 head-dim columns, 4 DMAs per lane per tile and sub-image.
-// NG = 2: two wave groups take alternate key tiles (FwdCfg); group 1's dQ partial is added by group 0 through LDS.
-template <int ND, int JQ, int NG>
+template <int ND, int JQ>
 struct DqCfg {
-  static constexpr int NST = (ND == 1 && NG == 1) ? 3 : 2;
+  static constexpr int NST = ND == 1 ? 3 : 2;
   static constexpr int STAGE = 2 * ND * IMG;
-  static constexpr int LDS = NG * NST * STAGE;
-  static constexpr int OCC = ND == 1 ? (NG == 2 ? 4 : JQ == 1 ? 3 : 2) : 2;
-  static constexpr bool PREFETCH = NG == 1;
+  static constexpr int OCC = ND == 1 ? (JQ == 1 ? 3 : 2) : 2;
 };
-template <int ND, int JQ, int NG>
-__global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_dq_kernel(AttnArgs p) {
-  constexpr int D = 64 * ND, STG = DqCfg<ND, JQ, NG>::STAGE, NST = DqCfg<ND, JQ, NG>::NST, QT = 64 * JQ, WR = 16 * JQ;
-  constexpr bool PF = DqCfg<ND, JQ, NG>::PREFETCH, STATIC_RING = NG == 2;
+template <int ND, int JQ>
+__global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, STG = DqCfg<ND, JQ>::STAGE, NST = DqCfg<ND, JQ>::NST, QT = 64 * JQ, WR = 16 * JQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.M, ld = p.ldq;
   const BlockItem bi = block_item(blockIdx.x, (M + QT - 1) / QT, p.nH, p.nKV);
@@ -537,28 +436,20 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
   const float c2 = p.scale * 1.44269504088896340736f;
-  const int gu = __builtin_amdgcn_readfirstlane(grp);
-  const uint32_t lds0 = lds_addr(smem) + (uint32_t)(gu * (NST * STG));  // this group's ring
+  const uint32_t lds0 = lds_addr(smem);
 
   const int kt_begin = p.seg_start[q0 < M ? q0 : M - 1] / 64;
   const int kt_end = (min(q0 + QT - 1, M - 1)) / 64;
-  const int n_all = kt_end - kt_begin + 1;
-  const int n = (n_all - gu + NG - 1) / NG, n_loop = (n_all + NG - 1) / NG;
+  const int n = kt_end - kt_begin + 1;
   TileOff off;
   off.init(ld, tid);
   FragOff fo;
   fo.init(l15, g);
-  if constexpr (STATIC_RING) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fo.d[i] += lds0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fo.t[i] += lds0;
-  }
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const size_t tstep = (size_t)64 * NG * ld;
-  const bf16_t* kp = Kb + (size_t)(kt_begin + gu) * 64 * ld;
-  const bf16_t* vp = Vb + (size_t)(kt_begin + gu) * 64 * ld;
-  int irow = (kt_begin + gu) * 64;
+  const size_t tstep = (size_t)64 * ld;
+  const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
+  const bf16_t* vp = Vb + (size_t)kt_begin * tstep;
+  int irow = kt_begin * 64;
   const uint32_t wdst = lds0 + (uint32_t)wv * 1024u;
   auto issue = [&](int stage) __attribute__((always_inline)) {
     const uint32_t st = wdst + (uint32_t)(stage * STG);
@@ -576,7 +467,7 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
         dma_tile64<false>(vp + dh * 64, off, mr, st + (ND + dh) * IMG);
       }
     }
-    kp += tstep; vp += tstep; irow += 64 * NG;
+    kp += tstep; vp += tstep; irow += 64;
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -607,7 +498,7 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
     dsm += __shfl_xor(dsm, 16, 64);
     dsm += __shfl_xor(dsm, 32, 64);
     nds[j] = -dsm;
-    if (g == 0 && q < M && grp == 0) {  // consumed by the dK/dV kernel (launched after this one)
+    if (g == 0 && q < M) {  // consumed by the dK/dV kernel (launched after this one)
       p.ndsum[(size_t)h * M + q] = -dsm;
       p.nlse[(size_t)h * M + q] = lse[j];
     }
@@ -621,22 +512,18 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
   wait_all_loads_visible();
 
   int stage = 0, istage = (NST - 1) % NST;
-  auto iter = [&](int t, auto sc) __attribute__((always_inline)) {
-    constexpr int S = decltype(sc)::value;
+  for (int t = 0; t < n; ++t) {
     if (NST >= 3 && t + 1 < n) wait_vmcnt<4 * ND>();
     else wait_vmcnt<0>();
     __syncthreads();
-    if (t + NST - 1 < n) issue(S >= 0 ? (S + NST - 1) % NST : istage);
+    if (t + NST - 1 < n) issue(istage);
+    istage = istage + 1 == NST ? 0 : istage + 1;
+    const uint32_t sb = lds0 + (uint32_t)(stage * STG);
+    stage = stage + 1 == NST ? 0 : stage + 1;
+    const int key0 = (kt_begin + t) * 64;
+    if (key0 > qw0 + WR - 1) continue;
     TileAddr ta;
-    if constexpr (S >= 0) {
-      ta.set_static(fo, S * STG);
-    } else {
-      istage = istage + 1 == NST ? 0 : istage + 1;
-      ta.set(fo, lds0 + (uint32_t)(stage * STG));
-      stage = stage + 1 == NST ? 0 : stage + 1;
-    }
-    const int key0 = (kt_begin + gu + t * NG) * 64;
-    if (t >= n || key0 > qw0 + WR - 1) return;
+    ta.set(fo, sb);
     f32x4_t st[4][JQ], dp[4][JQ];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -683,65 +570,23 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
       }
     };
     uint4 kt0[4 * ND];  // K^T fragments of the first contraction half: requested before the exp arithmetic, landing under it
-    if constexpr (PF) {
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd) kt0[fd] = ta.T((fd >> 2) * IMG, fd & 3, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int fd = 0; fd < 4 * ND; ++fd) kt0[fd] = ta.T((fd >> 2) * IMG, fd & 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if ((key0 + 63 > qw0) || (key0 < segmax_w) || (qw0 + WR - 1 >= M)) soft(std::true_type{});
     else soft(std::false_type{});
-    if constexpr (PF) {
-      __builtin_amdgcn_sched_barrier(0);
-      uint4 kt1[4 * ND];
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 kt1[4 * ND];
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd) kt1[fd] = ta.T((fd >> 2) * IMG, fd & 3, 1);
+    for (int fd = 0; fd < 4 * ND; ++fd) kt1[fd] = ta.T((fd >> 2) * IMG, fd & 3, 1);
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd)
+    for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
-        for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt0[fd], dsb[0][j], dq[j][fd]);
+      for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt0[fd], dsb[0][j], dq[j][fd]);
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd)
+    for (int fd = 0; fd < 4 * ND; ++fd)
 #pragma unroll
-        for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt1[fd], dsb[1][j], dq[j][fd]);
-    } else {
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd) {
-          const uint4 kt = ta.T((fd >> 2) * IMG, fd & 3, t2);
-#pragma unroll
-          for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt, dsb[t2][j], dq[j][fd]);
-        }
-    }
-  };
-  if constexpr (STATIC_RING) {
-    for (int t = 0; t < n_loop; t += 2) {
-      iter(t, std::integral_constant<int, 0>{});
-      if (t + 1 < n_loop) iter(t + 1, std::integral_constant<int, 1>{});
-    }
-  } else {
-    for (int t = 0; t < n_loop; ++t) iter(t, std::integral_constant<int, -1>{});
-  }
-  if constexpr (NG == 2) {  // group 1's partial sum -> LDS -> group 0 (lane-linear rows: conflict-free)
-    constexpr int NV = JQ * 4 * ND * 4;
-    __syncthreads();
-    float* xb = reinterpret_cast<float*>(smem) + (size_t)wave * (NV * 64) + lane;
-    if (grp == 1) {
-#pragma unroll
-      for (int j = 0; j < JQ; ++j)
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xb[((j * (4 * ND) + fd) * 4 + r) * 64] = dq[j][fd][r];
-    }
-    __syncthreads();
-    if (grp == 1) return;
-#pragma unroll
-    for (int j = 0; j < JQ; ++j)
-#pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dq[j][fd][r] += xb[((j * (4 * ND) + fd) * 4 + r) * 64];
+      for (int j = 0; j < JQ; ++j) dq[j][fd] = mfma16(kt1[fd], dsb[1][j], dq[j][fd]);
   }
 #pragma unroll
   for (int j = 0; j < JQ; ++j) {
@@ -782,15 +627,11 @@ __global__ __launch_bounds__(256 * NG, (DqCfg<ND, JQ, NG>::OCC)) void attn_bwd_d
 // head, the 64-row query tiles of its chunk: Q and dO tiles stream through the ring (one image each, read both ways), dK
 // and dV accumulate over ALL of it in registers. Stage = Q image + dO image (16 KB per 64 head-dim columns) + -lse2 /
 // -D / seg_start of the 64 query rows (3 x 256 B, by 4-byte LDS-DMA): 5 DMAs per lane per tile at head_dim 64.
-// NG = 2: two wave groups own the same keys and take alternate tiles of the (head, query tile) walk (FwdCfg); group 1's
-// dK / dV partials are added by group 0 through LDS before the slab is written.
-template <int ND, int KW, int NG>
+template <int ND, int KW>
 struct DkvCfg {
-  static constexpr int NST = (ND == 1 && NG == 1) ? 3 : 2;
+  static constexpr int NST = ND == 1 ? 3 : 2;
   static constexpr int STAGE = 2 * ND * IMG + 1024;
-  static constexpr int LDS = NG * NST * STAGE;
-  static constexpr int OCC = ND == 1 ? (NG == 2 ? 4 : KW == 1 ? 3 : 2) : 2;
-  static constexpr bool PREFETCH = KW == 1 && NG == 1;
+  static constexpr int OCC = ND == 1 ? (KW == 1 ? 3 : 2) : 2;
 };
 struct DkvRange { int qa, nq, nch; };
 // query tiles (64 rows) that can see the key tile [k0, k0 + KT), cut into at most `nchmax` chunks of equal length
@@ -805,14 +646,12 @@ SLAM_DEVICE DkvRange dkv_range(const int* seg_end, int M, int k0, int KT, int nc
   r.nq = min(cs, qt_end - r.qa + 1);
   return r;
 }
-template <int ND, int KW, int NG>
-__global__ __launch_bounds__(256 * NG, (DkvCfg<ND, KW, NG>::OCC)) void attn_bwd_dkv_kernel(AttnArgs p) {
-  constexpr int D = 64 * ND, STG = DkvCfg<ND, KW, NG>::STAGE, NST = DkvCfg<ND, KW, NG>::NST, KT = 64 * KW, WK = 16 * KW;
+template <int ND, int KW>
+__global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kernel(AttnArgs p) {
+  constexpr int D = 64 * ND, STG = DkvCfg<ND, KW>::STAGE, NST = DkvCfg<ND, KW>::NST, KT = 64 * KW, WK = 16 * KW;
   constexpr int NDMA = 4 * ND + 1;
-  constexpr bool STATIC_RING = NG == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.M, ld = p.ldq, ldo = p.nH * D;
   const int G = p.nH / p.nKV;
@@ -823,24 +662,16 @@ __global__ __launch_bounds__(256 * NG, (DkvCfg<ND, KW, NG>::OCC)) void attn_bwd_
   const int chunk = item & (NCH_MAX - 1), k0 = (item >> 2) * KT;
   const DkvRange rg = dkv_range(p.seg_end, M, k0, KT, p.nch, chunk);
   const int nq = rg.nq, qa = rg.qa;
-  const int gu = __builtin_amdgcn_readfirstlane(grp);
-  const int n_all = G * nq;
-  const int n = (n_all - gu + NG - 1) / NG, n_loop = (n_all + NG - 1) / NG;  // this group's tiles: gu, gu + NG, ... of the walk
+  const int n = G * nq;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
   const float c2 = p.scale * 1.44269504088896340736f;
-  const uint32_t lds0 = lds_addr(smem) + (uint32_t)(gu * (NST * STG));  // this group's ring
+  const uint32_t lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   TileOff qoff, ooff;
   qoff.init(ld, tid); ooff.init(ldo, tid);
   FragOff fo;
   fo.init(l15, g);
-  if constexpr (STATIC_RING) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fo.d[i] += lds0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fo.t[i] += lds0;
-  }
 
   // next tile to issue: running pointers of the (head, query tile) walk, all wave-uniform
   const size_t qstep = (size_t)64 * ld, ostep = (size_t)64 * ldo;
@@ -848,15 +679,6 @@ __global__ __launch_bounds__(256 * NG, (DkvCfg<ND, KW, NG>::OCC)) void attn_bwd_
   const bf16_t* dop = p.d_o + (size_t)(kvh * G) * D + (size_t)qa * ostep;
   int i_tq = 0, i_head = kvh * G, istage = 0, irow = qa * 64;
   const uint32_t wdst = lds0 + (uint32_t)wv * 1024u, sdst = lds0 + (uint32_t)(2 * ND * IMG) + (uint32_t)wv * 256u;
-  auto walk_step = [&]() __attribute__((always_inline)) {  // one tile further along (head, query tile)
-    qp += qstep; dop += ostep; irow += 64;
-    if (++i_tq == nq) {  // next head of the group: back to the chunk's first query tile
-      i_tq = 0;
-      ++i_head;
-      qp += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)qstep; dop += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)ostep;
-      irow -= nq * 64;
-    }
-  };
   auto issue_next = [&]() __attribute__((always_inline)) {
     const uint32_t st = wdst + (uint32_t)(istage * STG);
     const int mr = irow + 64 <= M ? 63 : M - 1 - irow;
@@ -879,11 +701,15 @@ __global__ __launch_bounds__(256 * NG, (DkvCfg<ND, KW, NG>::OCC)) void attn_bwd_
     const size_t hrow = (size_t)i_head * M + irow;
     const void* src = wv == 0 ? (const void*)(p.nlse + hrow) : wv == 1 ? (const void*)(p.ndsum + hrow) : (const void*)(p.seg_start + irow);
     glds4_m0(src, (uint32_t)(lane < mr ? lane : mr) * 4u, sdst + (uint32_t)(istage * STG));
-#pragma unroll
-    for (int k = 0; k < NG; ++k) walk_step();
+    qp += qstep; dop += ostep; irow += 64;
+    if (++i_tq == nq) {  // next head of the group: back to the chunk's first query tile
+      i_tq = 0;
+      ++i_head;
+      qp += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)qstep; dop += (ptrdiff_t)D - (ptrdiff_t)nq * (ptrdiff_t)ostep;
+      irow -= nq * 64;
+    }
     istage = istage + 1 == NST ? 0 : istage + 1;
   };
-  if (gu) walk_step();  // group 1 starts at the second tile of the walk
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < n) issue_next();
@@ -908,156 +734,104 @@ __global__ __launch_bounds__(256 * NG, (DkvCfg<ND, KW, NG>::OCC)) void attn_bwd_
   wait_all_loads_visible();
 
   const int kw0 = k0 + wave * WK;
-  int stage = 0, tq = nq > 0 ? gu % nq : 0;  // query tile (inside the chunk) of this group's current tile of the walk
-  auto iter = [&](int t, auto sc) __attribute__((always_inline)) {
-    constexpr int S = decltype(sc)::value;
+  int stage = 0, tq = 0;
+  for (int t = 0; t < n; ++t) {
     if (NST >= 3 && t + 1 < n) wait_vmcnt<NDMA>();
     else wait_vmcnt<0>();
     __syncthreads();
     if (t + NST - 1 < n) issue_next();
-    uint32_t sb;
-    TileAddr ta;
-    if constexpr (S >= 0) {
-      sb = lds0 + (uint32_t)(S * STG);
-      ta.set_static(fo, S * STG);
-    } else {
-      sb = lds0 + (uint32_t)(stage * STG);
-      ta.set(fo, sb);
-      stage = stage + 1 == NST ? 0 : stage + 1;
-    }
+    const uint32_t sb = lds0 + (uint32_t)(stage * STG);
+    stage = stage + 1 == NST ? 0 : stage + 1;
     const int qbase = (qa + tq) * 64;
-#pragma unroll
-    for (int k = 0; k < NG; ++k) tq = tq + 1 == nq ? 0 : tq + 1;
-    if (t >= n || qbase + 63 < kw0) return;  // no tile left for this group / no query of the tile can see this wave's keys
+    tq = tq + 1 == nq ? 0 : tq + 1;
+    if (qbase + 63 < kw0) continue;  // no query of the tile can see this wave's keys
+    TileAddr ta;
+    ta.set(fo, sb);
     uint32_t sca = sb + (uint32_t)(2 * ND * IMG + g * 16);  // per-row scalars of rows 16 jq + 4g .. +3
     asm volatile("" : "+v"(sca));
-    // latest segment start among the tile's query rows: row 63's (rows beyond M repeat row M-1)
-    const int segmax = *(__attribute__((address_space(3))) const int*)(lds_p(sb + (uint32_t)(2 * ND * IMG + 512 + 63 * 4)));
-    const bool need_mask = (kw0 + WK - 1 > qbase) || (kw0 < segmax) || (qbase + 63 >= M);
-    constexpr bool PF = DkvCfg<ND, KW, NG>::PREFETCH;  // (32 keys per wave / two wave groups: no registers left for it)
-    // NH query halves per tile: with two wave groups (128 registers per wave) the 64 query rows are processed as two halves of
-    // 32 - scores and dP, exp, then the dV / dK products of that contraction half - so that half the score registers and one
-    // packed fragment pair are live at a time
-    constexpr int NH = NG == 2 ? 2 : 1, JH = 4 / NH, TH = JH / 2;
+    f32x4_t s[4][KW], dp[4][KW];
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      f32x4_t s[JH][KW], dp[JH][KW];
+    for (int jq = 0; jq < 4; ++jq) {
+      const f32x4_t nl4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + jq * 64);
+      const f32x4_t nd4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + (256 + jq * 64));
 #pragma unroll
-      for (int jq = 0; jq < JH; ++jq) {
-        const f32x4_t nl4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + (hh * JH + jq) * 64);
-        const f32x4_t nd4 = *(__attribute__((address_space(3))) const f32x4_t*)(lds_p(sca) + (256 + (hh * JH + jq) * 64));
+      for (int i = 0; i < KW; ++i) { s[jq][i] = nl4; dp[jq][i] = nd4; }  // s - lse and dP - D for free: the accumulators start there
+    }
 #pragma unroll
-        for (int i = 0; i < KW; ++i) { s[jq][i] = nl4; dp[jq][i] = nd4; }  // s - lse and dP - D for free: the accumulators start there
+    for (int ds = 0; ds < 2 * ND; ++ds)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const uint4 qfr = ta.D((ds >> 1) * IMG, jq, ds & 1);
+        const uint4 dofr = ta.D((ND + (ds >> 1)) * IMG, jq, ds & 1);
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+          s[jq][i] = mfma16(qfr, kf[i][ds], s[jq][i]);
+          dp[jq][i] = mfma16(dofr, vf[i][ds], dp[jq][i]);
+        }
+      }
+    // lane holds (q = qbase + jq*16 + 4g + r, key[i]); mask only on diagonal / segment-boundary / tail tiles
+    uint4 pb[2][KW], dsb[2][KW];
+    auto soft = [&](auto mk) __attribute__((always_inline)) {
+      constexpr bool MASK = decltype(mk)::value;
+      int lo[KW], mh = 0;
+      if constexpr (MASK) {
+        mh = M - qbase - 4 * g;  // row 16 jq + r is a real query iff 16 jq + r < mh
+#pragma unroll
+        for (int i = 0; i < KW; ++i) lo[i] = key[i] - qbase - 4 * g;  // ... and sees key[i] iff 16 jq + r >= lo[i] (and the segment test)
       }
 #pragma unroll
-      for (int ds = 0; ds < 2 * ND; ++ds)
-#pragma unroll
-        for (int jq = 0; jq < JH; ++jq) {
-          const uint4 qfr = ta.D((ds >> 1) * IMG, hh * JH + jq, ds & 1);
-          const uint4 dofr = ta.D((ND + (ds >> 1)) * IMG, hh * JH + jq, ds & 1);
-#pragma unroll
-          for (int i = 0; i < KW; ++i) {
-            s[jq][i] = mfma16(qfr, kf[i][ds], s[jq][i]);
-            dp[jq][i] = mfma16(dofr, vf[i][ds], dp[jq][i]);
-          }
-        }
-      // lane holds (q = qbase + jq*16 + 4g + r, key[i]); mask only on diagonal / segment-boundary / tail tiles
-      uint4 pb[TH][KW], dsb[TH][KW];
-      auto soft = [&](auto mk) __attribute__((always_inline)) {
-        constexpr bool MASK = decltype(mk)::value;
-        int lo[KW], mh = 0;
+      for (int jq = 0; jq < 4; ++jq) {
+        int sv[4] = {0, 0, 0, 0};
         if constexpr (MASK) {
-          mh = M - qbase - 4 * g;  // row 16 jq + r is a real query iff 16 jq + r < mh
-#pragma unroll
-          for (int i = 0; i < KW; ++i) lo[i] = key[i] - qbase - 4 * g;  // ... and sees key[i] iff 16 jq + r >= lo[i] (and the segment test)
-        }
-#pragma unroll
-        for (int jq = 0; jq < JH; ++jq) {
-          const int jr = (hh * JH + jq) * 16;  // first row of this 16-row fragment inside the tile
-          int sv[4] = {0, 0, 0, 0};
-          if constexpr (MASK) {
-            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-            const i32x4_t s4 = *(__attribute__((address_space(3))) const i32x4_t*)(lds_p(sca) + (512 + (hh * JH + jq) * 64));
-            sv[0] = s4[0]; sv[1] = s4[1]; sv[2] = s4[2]; sv[3] = s4[3];
-          }
-#pragma unroll
-          for (int i = 0; i < KW; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pe = fast_exp2(s[jq][i][r]);
-              if constexpr (MASK) {
-                const bool ok = (jr + r >= lo[i]) & (jr + r < mh) & (key[i] >= sv[r]);
-                pe = ok ? pe : 0.f;
-              }
-              s[jq][i][r] = pe;
-              dp[jq][i][r] = pe * dp[jq][i][r];
-            }
+          typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+          const i32x4_t s4 = *(__attribute__((address_space(3))) const i32x4_t*)(lds_p(sca) + (512 + jq * 64));
+          sv[0] = s4[0]; sv[1] = s4[1]; sv[2] = s4[2]; sv[3] = s4[3];
         }
 #pragma unroll
         for (int i = 0; i < KW; ++i)
 #pragma unroll
-          for (int th = 0; th < TH; ++th) {
-            pb[th][i] = pack_pair(s[2 * th][i], s[2 * th + 1][i]);
-            dsb[th][i] = pack_pair(dp[2 * th][i], dp[2 * th + 1][i]);
-          }
-      };
-      uint4 dot0[4 * ND];  // dO^T fragments of the first contraction half: requested before the exp arithmetic
-      if constexpr (PF) {
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd) dot0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, hh * TH);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (need_mask) soft(std::true_type{});
-      else soft(std::false_type{});
-      if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int th = 0; th < TH; ++th)
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd) {
-          const uint4 dot = (PF && th == 0) ? dot0[fd] : ta.T((ND + (fd >> 2)) * IMG, fd & 3, hh * TH + th);
-          const uint4 qt = ta.T((fd >> 2) * IMG, fd & 3, hh * TH + th);
-#pragma unroll
-          for (int i = 0; i < KW; ++i) {
-            dv[i][fd] = mfma16(dot, pb[th][i], dv[i][fd]);
-            dk[i][fd] = mfma16(qt, dsb[th][i], dk[i][fd]);
-          }
-        }
-    }
-  };
-  if constexpr (STATIC_RING) {
-    for (int t = 0; t < n_loop; t += 2) {
-      iter(t, std::integral_constant<int, 0>{});
-      if (t + 1 < n_loop) iter(t + 1, std::integral_constant<int, 1>{});
-    }
-  } else {
-    for (int t = 0; t < n_loop; ++t) iter(t, std::integral_constant<int, -1>{});
-  }
-  if constexpr (NG == 2) {  // group 1's partial sums -> LDS -> group 0 (lane-linear rows: conflict-free)
-    constexpr int NV = KW * 4 * ND * 4 * 2;
-    __syncthreads();
-    float* xb = reinterpret_cast<float*>(smem) + (size_t)wave * (NV * 64) + lane;
-    if (grp == 1) {
-#pragma unroll
-      for (int i = 0; i < KW; ++i)
-#pragma unroll
-        for (int fd = 0; fd < 4 * ND; ++fd)
-#pragma unroll
           for (int r = 0; r < 4; ++r) {
-            xb[(((i * (4 * ND) + fd) * 4 + r) * 2 + 0) * 64] = dk[i][fd][r];
-            xb[(((i * (4 * ND) + fd) * 4 + r) * 2 + 1) * 64] = dv[i][fd][r];
+            float pe = fast_exp2(s[jq][i][r]);
+            if constexpr (MASK) {
+              const bool ok = (jq * 16 + r >= lo[i]) & (jq * 16 + r < mh) & (key[i] >= sv[r]);
+              pe = ok ? pe : 0.f;
+            }
+            s[jq][i][r] = pe;
+            dp[jq][i][r] = pe * dp[jq][i][r];
           }
+      }
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        pb[0][i] = pack_pair(s[0][i], s[1][i]);
+        pb[1][i] = pack_pair(s[2][i], s[3][i]);
+        dsb[0][i] = pack_pair(dp[0][i], dp[1][i]);
+        dsb[1][i] = pack_pair(dp[2][i], dp[3][i]);
+      }
+    };
+    // latest segment start among the tile's query rows: row 63's (rows beyond M repeat row M-1)
+    const int segmax = *(__attribute__((address_space(3))) const int*)(lds_p(sb + (uint32_t)(2 * ND * IMG + 512 + 63 * 4)));
+    constexpr bool PF = KW == 1;  // (32 keys per wave: no registers left for it)
+    uint4 dot0[4 * ND];  // dO^T fragments of the first contraction half: requested before the exp arithmetic
+    if constexpr (PF) {
+#pragma unroll
+      for (int fd = 0; fd < 4 * ND; ++fd) dot0[fd] = ta.T((ND + (fd >> 2)) * IMG, fd & 3, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    if (grp == 1) return;
+    if ((kw0 + WK - 1 > qbase) || (kw0 < segmax) || (qbase + 63 >= M)) soft(std::true_type{});
+    else soft(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < KW; ++i)
+    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int fd = 0; fd < 4 * ND; ++fd)
+      for (int fd = 0; fd < 4 * ND; ++fd) {
+        const uint4 dot = (PF && t2 == 0) ? dot0[fd] : ta.T((ND + (fd >> 2)) * IMG, fd & 3, t2);
+        const uint4 qt = ta.T((fd >> 2) * IMG, fd & 3, t2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dk[i][fd][r] += xb[(((i * (4 * ND) + fd) * 4 + r) * 2 + 0) * 64];
-          dv[i][fd][r] += xb[(((i * (4 * ND) + fd) * 4 + r) * 2 + 1) * 64];
+        for (int i = 0; i < KW; ++i) {
+          dv[i][fd] = mfma16(dot, pb[t2][i], dv[i][fd]);
+          dk[i][fd] = mfma16(qt, dsb[t2][i], dk[i][fd]);
         }
+      }
   }
 #pragma unroll
   for (int i = 0; i < KW; ++i)
@@ -1151,21 +925,19 @@ __global__ __launch_bounds__(1024) void attn_plan_kernel(const int* __restrict__
 
 namespace slam {
 
-static AttnTune g_attn_tune = {1, 1, 4, 0, 1};
+static AttnTune g_attn_tune = {1, 1, 4, 0};
 AttnTune attn_default_tune() { return g_attn_tune; }
 void attn_set_default_tune(AttnTune t) { g_attn_tune = t; }
 static AttnTune clamp_tune(AttnTune t, int head_dim) {
   t.jq = t.jq == 2 && head_dim == 64 ? 2 : 1;
   t.kw = t.kw == 2 && head_dim == 64 ? 2 : 1;
   t.nch = t.nch < 1 ? 1 : t.nch > NCH_MAX ? NCH_MAX : t.nch;
-  t.ng = t.ng == 2 && head_dim == 64 ? 2 : 1;
   return t;
 }
 
 size_t attn_plan_ints(int M) { return (size_t)((M + 127) / 128 + (M + 63) / 64 + NCH_MAX * ((M + 63) / 64)); }
 int attn_plan(const int* seg_start, const int* seg_end, int M, int head_dim, AttnTune tune, int* plan, hipStream_t st) {
   tune = clamp_tune(tune, head_dim);
-  if (tune.ng == 2) tune.jq = tune.kw = 1;
   const int qt = 64 * tune.jq, kt = 64 * tune.kw;
   const int total = (M + 127) / 128 + (M + qt - 1) / qt + NCH_MAX * ((M + kt - 1) / kt);
   if ((size_t)total * sizeof(int) > 48 * 1024) return -1;  // M beyond ~260k tokens per micro-batch: the work list no longer fits one block's LDS
@@ -1178,30 +950,30 @@ static int set_lds(K kernel, int bytes) {
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int ND, int NG>
+template <int ND>
 static int attn_fwd_nd(AttnArgs a, hipStream_t st) {
   static bool done = false;
-  constexpr int lds = FwdCfg<ND, NG>::LDS;
-  if (!done) { if (int e = set_lds(&attn_fwd_kernel<ND, NG>, lds)) return e; done = true; }
-  attn_fwd_kernel<ND, NG><<<item_grid((a.M + 127) / 128, a.nH, a.nKV), 256 * NG, lds, st>>>(a);
+  constexpr int lds = FwdCfg<ND>::NST * FwdCfg<ND>::STAGE;
+  if (!done) { if (int e = set_lds(&attn_fwd_kernel<ND>, lds)) return e; done = true; }
+  attn_fwd_kernel<ND><<<item_grid((a.M + 127) / 128, a.nH, a.nKV), 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
-template <int ND, int JQ, int NG>
+template <int ND, int JQ>
 static int attn_dq_launch(AttnArgs a, hipStream_t st) {
   static bool done = false;
-  constexpr int lds = DqCfg<ND, JQ, NG>::LDS;
-  if (!done) { if (int e = set_lds(&attn_bwd_dq_kernel<ND, JQ, NG>, lds)) return e; done = true; }
-  attn_bwd_dq_kernel<ND, JQ, NG><<<item_grid((a.M + 64 * JQ - 1) / (64 * JQ), a.nH, a.nKV), 256 * NG, lds, st>>>(a);
+  constexpr int lds = DqCfg<ND, JQ>::NST * DqCfg<ND, JQ>::STAGE;
+  if (!done) { if (int e = set_lds(&attn_bwd_dq_kernel<ND, JQ>, lds)) return e; done = true; }
+  attn_bwd_dq_kernel<ND, JQ><<<item_grid((a.M + 64 * JQ - 1) / (64 * JQ), a.nH, a.nKV), 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
-template <int ND, int KW, int NG>
+template <int ND, int KW>
 static int attn_dkv_launch(AttnArgs a, hipStream_t st) {
   static bool done = false;
-  constexpr int lds = DkvCfg<ND, KW, NG>::LDS;
-  if (!done) { if (int e = set_lds(&attn_bwd_dkv_kernel<ND, KW, NG>, lds)) return e; done = true; }
+  constexpr int lds = DkvCfg<ND, KW>::NST * DkvCfg<ND, KW>::STAGE;
+  if (!done) { if (int e = set_lds(&attn_bwd_dkv_kernel<ND, KW>, lds)) return e; done = true; }
   const int nk = (a.M + 64 * KW - 1) / (64 * KW);
-  attn_bwd_dkv_kernel<ND, KW, NG><<<nk * NCH_MAX * a.nKV, 256 * NG, lds, st>>>(a);
+  attn_bwd_dkv_kernel<ND, KW><<<nk * NCH_MAX * a.nKV, 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -1211,8 +983,7 @@ int attn_fwd(const bf16_t* qkv, bf16_t* o, float* lse2, const int* seg_start, co
   AttnArgs a{};
   a.qkv = qkv; a.o = o; a.lse2 = lse2; a.seg_start = seg_start; a.perm = plan; a.prio = tune.prio;
   a.M = M; a.nH = nH; a.nKV = nKV; a.ldq = (nH + 2 * nKV) * head_dim; a.scale = 1.0f / sqrtf((float)head_dim);
-  if (head_dim == 128) return attn_fwd_nd<2, 1>(a, st);
-  return tune.ng == 2 ? attn_fwd_nd<1, 2>(a, st) : attn_fwd_nd<1, 1>(a, st);
+  return head_dim == 64 ? attn_fwd_nd<1>(a, st) : attn_fwd_nd<2>(a, st);
 }
 
 size_t attn_bwd_workspace_bytes(int M, int nKV, int head_dim) {
@@ -1224,7 +995,6 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
              const float* rope_cs, const float* rope_sn, int M, int nH, int nKV, int head_dim, hipStream_t st) {
   if ((head_dim != 64 && head_dim != 128) || nH % nKV || !plan) return -1;
   tune = clamp_tune(tune, head_dim);
-  if (tune.ng == 2) tune.jq = tune.kw = 1;
   AttnArgs a{};
   a.qkv = qkv; a.o = const_cast<bf16_t*>(o); a.d_o = d_o; a.dqkv = dqkv;
   a.lse2 = const_cast<float*>(lse2); a.ndsum = ndsum; a.nlse = nlse; a.dkv_part = dkv_part;
@@ -1235,14 +1005,12 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
   const int nf = (M + 127) / 128, qt = 64 * tune.jq, kt = 64 * tune.kw;
   a.perm = plan + nf;
   int e;
-  if (head_dim == 128) e = attn_dq_launch<2, 1, 1>(a, st);
-  else if (tune.ng == 2) e = attn_dq_launch<1, 1, 2>(a, st);  // (two wave groups: 16 query rows per wave)
-  else e = tune.jq == 2 ? attn_dq_launch<1, 2, 1>(a, st) : attn_dq_launch<1, 1, 1>(a, st);
+  if (head_dim == 128) e = attn_dq_launch<2, 1>(a, st);
+  else e = tune.jq == 2 ? attn_dq_launch<1, 2>(a, st) : attn_dq_launch<1, 1>(a, st);
   if (e) return e;
   a.perm = plan + nf + (M + qt - 1) / qt;
-  if (head_dim == 128) e = attn_dkv_launch<2, 1, 1>(a, st);
-  else if (tune.ng == 2) e = attn_dkv_launch<1, 1, 2>(a, st);
-  else e = tune.kw == 2 ? attn_dkv_launch<1, 2, 1>(a, st) : attn_dkv_launch<1, 1, 1>(a, st);
+  if (head_dim == 128) e = attn_dkv_launch<2, 1>(a, st);
+  else e = tune.kw == 2 ? attn_dkv_launch<1, 2>(a, st) : attn_dkv_launch<1, 1>(a, st);
   if (e) return e;
   const size_t total = (size_t)2 * M * nKV * (head_dim / 8);
   if (head_dim == 128) attn_dkv_reduce_kernel<2><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, kt);

@@ -468,11 +468,11 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     if (gemm_tune_set(h ? &h->gemm_tune : gemm_default_tune(), key, (long)value)) return SLAM_OK;
     return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
   }
-  if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch") || !strcmp(key, "attn_prio") || !strcmp(key, "attn_ng")) {
+  if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch") || !strcmp(key, "attn_prio")) {
     // with an engine: that engine's launches (takes effect at its next forward, which rebuilds the attention plan);
     // without: the process default picked up by the single-op entry points and by engines created afterwards
     AttnTune t = h ? h->attn_tune : attn_default_tune();
-    (key[5] == 'j' ? t.jq : key[5] == 'k' ? t.kw : !strcmp(key, "attn_nch") ? t.nch : !strcmp(key, "attn_ng") ? t.ng : t.prio) = (int)value;
+    (key[5] == 'j' ? t.jq : key[5] == 'k' ? t.kw : key[5] == 'n' ? t.nch : t.prio) = (int)value;
     if (h) { h->attn_tune = t; h->have_fwd = false; } else attn_set_default_tune(t);
     return SLAM_OK;
   }

@@ -51,7 +51,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
 // attention.hip
 // launch-shape choices of the backward kernels (engine-owned, "attn_jq" / "attn_kw" / "attn_nch" options):
 // jq / kw = 16-row fragments per wave in dQ / dK-dV (1 or 2; head_dim 64 only), nch = query-range chunks per key tile (1..4)
-struct AttnTune { int jq, kw, nch, prio, ng; };  // prio: s_setprio by LPT rank (0 = off); ng: wave groups per block (1 or 2)
+struct AttnTune { int jq, kw, nch, prio; };  // prio: s_setprio by LPT rank (0 = off)
 AttnTune attn_default_tune();
 void attn_set_default_tune(AttnTune t);
 size_t attn_plan_ints(int M);

@@ -324,25 +324,6 @@ def _attn_ref(qkv, seg_s, nH, nKV, d_o=None, hd=64):
     ([64], 2, 1, False, 128), ([200], 4, 2, True, 128), ([256, 256], 12, 2, False, 128),
     ([37, 100, 5, 130, 64], 4, 2, False, 128), ([1024], 6, 1, False, 128), ([29, 41, 17], 4, 2, True, 128)])
 def test_attention_fwd_bwd(seg_lens, nH, nKV, spike, hd):
-    _attention_fwd_bwd(seg_lens, nH, nKV, spike, hd)
-
-
-@pytest.mark.parametrize("seg_lens,nH,nKV,spike", [
-    ([64], 2, 1, False), ([128], 2, 2, False), ([200], 4, 2, True), ([256, 256], 14, 2, False),
-    ([37, 100, 5, 130, 64], 4, 2, False), ([1024], 7, 1, False), ([29, 41, 17], 4, 2, True), ([700, 324], 6, 3, False),
-    ([1, 63, 64, 65, 127, 3], 4, 2, True)])
-def test_attention_two_wave_groups(seg_lens, nH, nKV, spike):
-    """"attn_ng" = 2: blocks of two wave groups that split the key range (forward, dQ) / the (head, query tile) walk (dK/dV)
-    and merge through LDS - forward (O, lse) and all three gradients against the same fp32 reference and bars."""
-    L = lib()
-    try:
-        assert L.slam_set_option(None, b"attn_ng", 2) == 0
-        _attention_fwd_bwd(seg_lens, nH, nKV, spike, 64)
-    finally:
-        L.slam_set_option(None, b"attn_ng", 1)
-
-
-def _attention_fwd_bwd(seg_lens, nH, nKV, spike, hd):
     M, ld, qkv, seg_s, seg_e = _attn_case(seg_lens, nH, nKV, seed=len(seg_lens), spike=spike, hd=hd)
     d_o = rnd(M, nH * hd, seed=9)
     o_ref, dqkv_ref = _attn_ref(qkv, seg_s, nH, nKV, d_o, hd=hd)
@@ -377,11 +358,10 @@ def _attention_fwd_bwd(seg_lens, nH, nKV, spike, hd):
 _ATTN_REF_CACHE = {}
 
 
-@pytest.mark.parametrize("jq,kw,nch,ng", [(2, 1, 4, 1), (1, 2, 4, 1), (2, 2, 1, 1), (1, 1, 1, 1), (1, 1, 2, 1), (2, 2, 3, 1),
-                                          (1, 1, 4, 2), (1, 1, 2, 2), (1, 1, 1, 2)])
+@pytest.mark.parametrize("jq,kw,nch", [(2, 1, 4), (1, 2, 4), (2, 2, 1), (1, 1, 1), (1, 1, 2), (2, 2, 3)])
 @pytest.mark.parametrize("seg_lens,nH,nKV", [([256, 256], 14, 2), ([37, 100, 5, 130, 64], 4, 2), ([1024], 7, 1),
                                              ([29, 41, 17], 4, 2), ([700, 324], 6, 3)])
-def test_attention_bwd_launch_shapes(seg_lens, nH, nKV, jq, kw, nch, ng):
+def test_attention_bwd_launch_shapes(seg_lens, nH, nKV, jq, kw, nch):
     """Every launch shape of the backward (rows per wave in dQ, keys per wave in dK/dV, query-range chunks per key tile)
     against the fp32 reference, and bit-reproducible; head_dim 64 (the shapes only exist there)."""
     hd = 64
@@ -397,7 +377,7 @@ def test_attention_bwd_launch_shapes(seg_lens, nH, nKV, jq, kw, nch, ng):
     ss, se = seg_s.cuda(), seg_e.cuda()
     L = lib()
     try:
-        for k, v in (("attn_jq", jq), ("attn_kw", kw), ("attn_nch", nch), ("attn_ng", ng)):
+        for k, v in (("attn_jq", jq), ("attn_kw", kw), ("attn_nch", nch)):
             assert L.slam_set_option(None, k.encode(), v) == 0
         assert L.slam_op_attn_fwd(ptr(qd), ptr(o), ptr(lse), ptr(ss), M, nH, nKV, hd, stream()) == 0
         ws = torch.empty(L.slam_op_attn_bwd_workspace(M, nH, hd) // 4 + 16, dtype=torch.float32, device="cuda")
@@ -409,7 +389,7 @@ def test_attention_bwd_launch_shapes(seg_lens, nH, nKV, jq, kw, nch, ng):
             sync()
             outs.append(dqkv)
     finally:
-        for k, v in (("attn_jq", 1), ("attn_kw", 1), ("attn_nch", 4), ("attn_ng", 1)):
+        for k, v in (("attn_jq", 1), ("attn_kw", 1), ("attn_nch", 4)):
             L.slam_set_option(None, k.encode(), v)
     assert torch.equal(outs[0], outs[1]), "attention backward is not bit-reproducible"
     got = outs[0].float().cpu()

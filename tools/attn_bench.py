@@ -57,8 +57,8 @@ for shape in a.shapes.split(","):
         tunes = a.tunes.split(",") if libname == "new" else ["-"]
         for tune in tunes:
             if tune != "-":
-                jq, kw, nch, prio, ng = ([int(x) for x in tune.split(".")] + [0, 1])[:5]
-                for k, v in (("attn_jq", jq), ("attn_kw", kw), ("attn_nch", nch), ("attn_prio", prio), ("attn_ng", ng)):
+                jq, kw, nch, prio = ([int(x) for x in tune.split(".")] + [0])[:4]
+                for k, v in (("attn_jq", jq), ("attn_kw", kw), ("attn_nch", nch), ("attn_prio", prio)):
                     assert lib.slam_set_option(None, k.encode(), v) == 0
             f = timeit(lambda: lib.slam_op_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), ss.data_ptr(), M, nH, nKV, HD, st), a.iters)
             b = timeit(lambda: lib.slam_op_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), ss.data_ptr(), se.data_ptr(), M, nH, nKV, HD, st), a.iters)
