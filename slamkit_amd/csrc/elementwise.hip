@@ -654,24 +654,29 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x,
 // ranges - the whole buffer on one GPU, one 1/N shard per bucket per rank under the sharded optimizer - produces the
 // same chunk sums bit for bit; norm_finish_kernel adds them in fp64 in chunk order.
 constexpr int GRAD_CHUNK = 8192;
-__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, size_t n, size_t first_chunk,
+constexpr int CHUNKS_PER_BLOCK = 16;  // a block walks 16 consecutive chunks (512 KB): fewer, longer blocks stream better
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, size_t n, size_t first_chunk, size_t n_chunks,
                                                            float* __restrict__ chunk_sums) {
-  __shared__ float red[4];
-  const size_t k = first_chunk + blockIdx.x;
-  const size_t lo = k * GRAD_CHUNK, hi = lo + GRAD_CHUNK < n ? lo + GRAD_CHUNK : n;
-  float s = 0.f;
+  __shared__ float red[CHUNKS_PER_BLOCK][4];
+  const size_t kb = (size_t)blockIdx.x * CHUNKS_PER_BLOCK;
+  for (int c = 0; c < CHUNKS_PER_BLOCK && kb + c < n_chunks; ++c) {
+    const size_t k = first_chunk + kb + c;
+    const size_t lo = k * GRAD_CHUNK, hi = lo + GRAD_CHUNK < n ? lo + GRAD_CHUNK : n;
+    float4 v[GRAD_CHUNK / 1024];
 #pragma unroll
-  for (int it = 0; it < GRAD_CHUNK / 1024; ++it) {
-    const size_t i = lo + (size_t)(it * 256 + threadIdx.x) * 4;
-    if (i < hi) {
-      float4 v = *reinterpret_cast<const float4*>(g + i);
-      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    for (int it = 0; it < GRAD_CHUNK / 1024; ++it) {  // all eight loads in flight before the first add
+      const size_t i = lo + (size_t)(it * 256 + threadIdx.x) * 4;
+      v[it] = i < hi ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < GRAD_CHUNK / 1024; ++it) s += v[it].x * v[it].x + v[it].y * v[it].y + v[it].z * v[it].z + v[it].w * v[it].w;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = s;
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) chunk_sums[k] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x < CHUNKS_PER_BLOCK && kb + threadIdx.x < n_chunks)
+    chunk_sums[first_chunk + kb + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 // out[0] = ||g||, out[1] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 when max_norm<=0)
 __global__ void norm_finish_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
@@ -1028,8 +1033,8 @@ int grad_chunk_elems() { return GRAD_CHUNK; }
 int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st) {
   if ((n & 3) || (off % GRAD_CHUNK) || off + cnt > n || (((off + cnt) % GRAD_CHUNK) && off + cnt != n)) return -1;
   if (cnt == 0) return 0;
-  const size_t nb = (cnt + GRAD_CHUNK - 1) / GRAD_CHUNK;
-  sumsq_chunks_kernel<<<(unsigned)nb, 256, 0, st>>>(g, n, off / GRAD_CHUNK, chunk_sums);
+  const size_t nc = (cnt + GRAD_CHUNK - 1) / GRAD_CHUNK;
+  sumsq_chunks_kernel<<<(unsigned)((nc + CHUNKS_PER_BLOCK - 1) / CHUNKS_PER_BLOCK), 256, 0, st>>>(g, n, off / GRAD_CHUNK, nc, chunk_sums);
   LAUNCH_RET();
 }
 int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st) {

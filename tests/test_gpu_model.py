@@ -532,5 +532,7 @@ def test_configs3_full_depth_packed_vs_oracle():
     # (bf16) changes in its last bit, D = rowsum(dO * O) with it, and dS = P (dP - D) - a difference of nearly equal terms -
     # by ~1 % per layer on the q / k projections (tools/diag_perm.py: 1.2 % worst tensor at 2 layers, 3.7 % of the flat
     # gradient at 28). That is the precision's own noise (the same tensors sit at cosine 0.999 against the fp32 oracle): the
-    # permuted run has to agree to that bar, the loss to fp32 summation order.
-    assert abs(l2 - l0) <= 1e-4 and rel_err(g2, g0) <= 6e-2 and cosine(g2, g0) >= 0.998
+    # permuted run has to agree to that bar; the loss (ln 152167 = 11.9) to 5e-4: the attention probabilities are rounded
+    # to bf16 relative to a running max that depends on where a sequence falls against the 64-key tiles, so O - and with it
+    # the loss - moves by bf16 rounding noise under the permutation (measured 1.7e-4 = 1.4e-5 relative at 28 layers).
+    assert abs(l2 - l0) <= 5e-4 and rel_err(g2, g0) <= 6e-2 and cosine(g2, g0) >= 0.998
