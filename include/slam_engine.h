@@ -215,6 +215,9 @@ int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, int head_dim,
                  int backward, float* cos_sin_ws /* 2*M*(head_dim/2) floats */, slam_stream_t s);
 int slam_op_swiglu_fwd(const void* gu, void* act, int M, int I, slam_stream_t s);
 int slam_op_swiglu_bwd(void* gu_inout, const void* dact, int M, int I, slam_stream_t s);
+/* attention ops: the QUERY columns of qkv are expected PRE-SCALED by head_dim^-0.5 * log2(e) (the engine's QKV projection
+ * folds that factor into the queries' RoPE rotation: one rounding); dqkv's query columns come back as the gradient of
+ * the UNSCALED queries. */
 int slam_op_attn_fwd(const void* qkv, void* o, float* lse2, const int32_t* seg_start, int M, int nH, int nKV,
                      int head_dim, slam_stream_t s);
 size_t slam_op_attn_bwd_workspace(int M, int nH, int head_dim);

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // RoPE tables (fp32 cos/sin [M][hd/2]) from positions; position_ids == nullptr -> m % T.
 __global__ void rope_table_kernel(const int64_t* __restrict__ pos, int M, int T, int half, float theta,
-                                  float* __restrict__ cs, float* __restrict__ sn) {
+                                  float* __restrict__ cs, float* __restrict__ sn, float* __restrict__ csq,
+                                  float* __restrict__ snq, float qscale) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * half) return;
   int m = i / half, d = i % half;
@@ -229,13 +230,17 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, int M, int T,
   sincosf(a, &s, &c);
   cs[i] = c;
   sn[i] = s;
+  if (csq) {  // the query heads' table: the rotation and the softmax scale * log2(e) in one multiply (attention.hip)
+    csq[i] = c * qscale;
+    snq[i] = s * qscale;
+  }
 }
 
 // In-place rotate-half RoPE on the first `nrot` heads of each row of qkv [M][ld] (head_dim hd, a
 // multiple of 16). dir = +1 forward, -1 backward (transpose rotation).
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, int M, int nrot, int hd,
                                                    const float* __restrict__ cs, const float* __restrict__ sn,
-                                                   float dir) {
+                                                   float dir, int q_heads, float q_scale) {
   // one thread: 8 low-half elems + their 8 high-half partners of one head; hd/16 threads per head
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int tph = hd >> 4, half = hd >> 1;
@@ -253,11 +258,12 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int
   *reinterpret_cast<float4*>(c) = cp[0]; *reinterpret_cast<float4*>(c + 4) = cp[1];
   *reinterpret_cast<float4*>(s) = sp[0]; *reinterpret_cast<float4*>(s + 4) = sp[1];
   float o1[8], o2[8];
+  const float hs = head < q_heads ? q_scale : 1.f;  // query heads leave pre-scaled by scale * log2(e)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float sj = s[j] * dir;
-    o1[j] = a[j] * c[j] - b[j] * sj;
-    o2[j] = b[j] * c[j] + a[j] * sj;
+    o1[j] = (a[j] * c[j] - b[j] * sj) * hs;
+    o2[j] = (b[j] * c[j] + a[j] * sj) * hs;
   }
   *reinterpret_cast<uint4*>(base) = pack_bf16x8(o1);
   *reinterpret_cast<uint4*>(base + half) = pack_bf16x8(o2);
@@ -948,17 +954,18 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   LAUNCH_RET();
 }
 
-int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st) {
+int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, float* csq, float* snq,
+               float qscale, hipStream_t st) {
   int half = head_dim / 2;
-  rope_table_kernel<<<nblocks((size_t)M * half, 256), 256, 0, st>>>(pos, M, T, half, theta, cs, sn);
+  rope_table_kernel<<<nblocks((size_t)M * half, 256), 256, 0, st>>>(pos, M, T, half, theta, cs, sn, csq, snq, qscale);
   LAUNCH_RET();
 }
 
 int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, int head_dim, const float* cs, const float* sn, int backward,
-               hipStream_t st) {
+               hipStream_t st, int q_heads, float q_scale) {
   if (head_dim & 15) return -1;
   rope_kernel<<<nblocks((size_t)M * nrot_heads * (head_dim / 16), 256), 256, 0, st>>>(qkv, ld, M, nrot_heads, head_dim, cs, sn,
-                                                                                     backward ? -1.f : 1.f);
+                                                                                     backward ? -1.f : 1.f, q_heads, q_scale);
   LAUNCH_RET();
 }
 

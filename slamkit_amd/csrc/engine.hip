@@ -107,6 +107,7 @@ struct SlamEngine {
   size_t pw_used = 0;
   bool params_t_dirty = false;     // ranged optimizer updates leave the transposed weight images stale until backward needs them
   float* nlse = nullptr;
+  float *cosq = nullptr, *sinq = nullptr;  // the query heads' RoPE tables: cos / sin times head_dim^-0.5 * log2(e)
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
@@ -195,6 +196,8 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->dkv_part = c.take<float>(attn_bwd_workspace_bytes((int)M, d.n_kv_heads, d.head_dim) / sizeof(float));
   e->cosb = c.take<float>(M * (d.head_dim / 2));
   e->sinb = c.take<float>(M * (d.head_dim / 2));
+  e->cosq = c.take<float>(M * (d.head_dim / 2));
+  e->sinq = c.take<float>(M * (d.head_dim / 2));
   e->seg_s = c.take<int>(M);
   e->seg_e = c.take<int>(M);
   e->attn_plan_buf = c.take<int>(attn_plan_ints((int)M));
@@ -512,7 +515,10 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     h->cur_seg_e = h->seg_e;
   }
   CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, d.head_dim, h->attn_tune, h->attn_plan_buf, st));
-  CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, st));
+  // queries are stored pre-scaled by head_dim^-0.5 * log2(e) (folded into their rotation tables: one rounding), so the
+  // attention kernels' scores leave the matrix pipe in the exp2 domain
+  const float qscale = 1.44269504088896340736f / sqrtf((float)d.head_dim);
+  CK(rope_table(position_ids, M, T, d.head_dim, d.rope_theta, h->cosb, h->sinb, h->cosq, h->sinq, qscale, st));
   CK(wait_chunk(h, 0, st));
   CK(wait_params(h, h->off_embed, h->lo[0].ln1, st));
   CK(embed_fwd(ids, P + h->off_embed, h->hs[0], M, H, d.vocab, st));
@@ -523,10 +529,10 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(wait_params(h, o.ln1, o.ln1 + h->layer_stride, st));
     CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
     if (d.head_dim == 64 && (H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
-      CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, nH + nKV, M, h->QKV, H, st));
+      CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, h->cosq, h->sinq, nH, nH + nKV, M, h->QKV, H, st));
     } else {
       CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
-      CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, d.head_dim, h->cosb, h->sinb, 0, st));
+      CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, d.head_dim, h->cosb, h->sinb, 0, st, nH, qscale));
     }
     CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, h->attn_tune, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
@@ -937,7 +943,7 @@ int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const floa
 int slam_op_rope(void* qkv, int ld, int M, int T, int n_rot_heads, int head_dim, const int64_t* position_ids, float theta,
                  int backward, float* cs_ws, slam_stream_t s) {
   const size_t half = (size_t)head_dim / 2;
-  int r = rope_table(position_ids, M, T, head_dim, theta, cs_ws, cs_ws + (size_t)M * half, (hipStream_t)s);
+  int r = rope_table(position_ids, M, T, head_dim, theta, cs_ws, cs_ws + (size_t)M * half, nullptr, nullptr, 1.f, (hipStream_t)s);
   if (r) return r;
   return rope_apply((bf16_t*)qkv, ld, M, n_rot_heads, head_dim, cs_ws, cs_ws + (size_t)M * half, backward, (hipStream_t)s);
 }

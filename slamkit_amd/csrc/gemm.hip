@@ -87,6 +87,9 @@ struct GemmArgs {
   int rope_heads;
   int group_rows;  // tile rasterisation group height (0/1 = plain row-major)
   int nt_store;    // streaming (non-temporal) output stores: large outputs must not evict the operand panels from L2
+  const float* rope_cos_q;  // tables of the first rope_q_heads heads (queries: pre-scaled, kernels.h rope_table)
+  const float* rope_sin_q;
+  int rope_q_heads;
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -240,10 +243,12 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
   struct Fields {  // what the fused paths read; LEAN pins the optional operands to null at compile time
     void* C; bf16_t* act; bf16_t* gu; int R, Cn, ldc, nt_store;
     const bf16_t* bias; const bf16_t* resid; const float* rope_cos; const float* rope_sin; int rope_heads;
+    const float* rope_cos_q; const float* rope_sin_q; int rope_q_heads;
   };
   const Fields p = {p_.C, p_.act, p_.gu, p_.R, p_.Cn, p_.ldc, p_.nt_store,
                   LEAN ? nullptr : p_.bias, LEAN ? nullptr : p_.resid, LEAN ? nullptr : p_.rope_cos,
-                  LEAN ? nullptr : p_.rope_sin, LEAN ? 0 : p_.rope_heads};
+                  LEAN ? nullptr : p_.rope_sin, LEAN ? 0 : p_.rope_heads,
+                  LEAN ? nullptr : p_.rope_cos_q, LEAN ? nullptr : p_.rope_sin_q, LEAN ? 0 : p_.rope_q_heads};
   // lane holds C[m][cq(q) .. +7] for q = 0, 1 in fragments (2q, 2q+1): 16-byte accesses throughout
   const int cw = col0 + wn * 64 + g * 8;  // + 32 q
   uint4 bb4[2];
@@ -313,8 +318,9 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
     }
     // fused RoPE: the wave's 64 columns are one head; q = 0 / 1 hold d and d + 32 of the same lane
     if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
-      const float4* cp = reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + g * 8);
-      const float4* sp = reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + g * 8);
+      const bool qh = ((col0 + wn * 64) >> 6) < p.rope_q_heads;  // wave-uniform: the wave's 64 columns are one head
+      const float4* cp = reinterpret_cast<const float4*>((qh ? p.rope_cos_q : p.rope_cos) + (size_t)m * 32 + g * 8);
+      const float4* sp = reinterpret_cast<const float4*>((qh ? p.rope_sin_q : p.rope_sin) + (size_t)m * 32 + g * 8);
       float cc[8], ss[8];
       *reinterpret_cast<float4*>(cc) = cp[0]; *reinterpret_cast<float4*>(cc + 4) = cp[1];
       *reinterpret_cast<float4*>(ss) = sp[0]; *reinterpret_cast<float4*>(ss + 4) = sp[1];
@@ -612,10 +618,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       if constexpr (NF == 4) {
         // fused RoPE: the wave's 64 columns are one head; fragments fn and fn+2 hold d and d+32
         if (p.rope_cos && mok && ((col0 + wn * 64) >> 6) < p.rope_heads) {
+          const bool qh = ((col0 + wn * 64) >> 6) < p.rope_q_heads;
+          const float* ct = qh ? p.rope_cos_q : p.rope_cos;
+          const float* stb = qh ? p.rope_sin_q : p.rope_sin;
 #pragma unroll
           for (int fn = 0; fn < 2; ++fn) {
-            const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)m * 32 + fn * 16 + g * 4);
-            const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)m * 32 + fn * 16 + g * 4);
+            const float4 c4 = *reinterpret_cast<const float4*>(ct + (size_t)m * 32 + fn * 16 + g * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(stb + (size_t)m * 32 + fn * 16 + g * 4);
             const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1592,9 +1601,10 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
 
 // QKV projection with bias and rotate-half RoPE applied to the first rope_heads heads in the epilogue
 int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const float* cs, const float* sn,
-                 int rope_heads, int M, int N, int K, hipStream_t st) {
+                 const float* csq, const float* snq, int q_heads, int rope_heads, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN)) return -1;
   GemmArgs a{X, W, Y, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN, cs, sn, rope_heads};
+  a.rope_cos_q = csq ? csq : cs; a.rope_sin_q = snq ? snq : sn; a.rope_q_heads = csq ? q_heads : 0;
   return launch_nt_dma(a, st);
 }
 

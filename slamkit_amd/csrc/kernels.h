@@ -35,8 +35,9 @@ int gemm_nt(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, con
             int K, hipStream_t st);
 // same, and additionally act[M][N/2] = silu(gate) * up for W rows laid out in 32-row gate/up blocks
 int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int M, int N, int K, hipStream_t st);
+// rotate-half RoPE on the first rope_heads 64-column heads; the first q_heads of them with the (pre-scaled) csq / snq tables
 int gemm_nt_rope(const bf16_t* X, const bf16_t* W, bf16_t* Y, const bf16_t* bias, const float* cs, const float* sn,
-                 int rope_heads, int M, int N, int K, hipStream_t st);
+                 const float* csq, const float* snq, int q_heads, int rope_heads, int M, int N, int K, hipStream_t st);
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st);
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st);
@@ -74,9 +75,12 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st);
 int colsum_blocks(int M);
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st);
-int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, hipStream_t st);
+// csq / snq (nullable): the same tables times qscale - the QUERY heads are rotated with these, so that q is stored
+// pre-scaled by head_dim^-0.5 * log2(e) (one rounding): the attention kernels' scores come out in the exp2 domain
+int rope_table(const int64_t* pos, int M, int T, int head_dim, float theta, float* cs, float* sn, float* csq, float* snq,
+               float qscale, hipStream_t st);
 int rope_apply(bf16_t* qkv, int ld, int M, int nrot_heads, int head_dim, const float* cs, const float* sn, int backward,
-               hipStream_t st);
+               hipStream_t st, int q_heads = 0, float q_scale = 1.f);
 int swiglu_fwd(const bf16_t* gu, bf16_t* act, int M, int I, int blk, hipStream_t st);
 int swiglu_bwd(bf16_t* gu, const bf16_t* dact, int M, int I, int blk, hipStream_t st);
 int embed_fwd(const int64_t* ids, const bf16_t* E, bf16_t* out, int M, int H, int V, hipStream_t st);
