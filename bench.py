@@ -145,15 +145,30 @@ def kernel_rooflines(model, iters=30, warm=10):
     p = lambda t: t.data_ptr()  # noqa: E731
     add("gate|up fwd + SwiGLU (NT 256x256 8-phase, persistent) M8192 N9728 K896", 2.0 * M * 2 * I * H,
         lambda: lib.slam_op_gemm_nt_swiglu(p(x), p(wgu), p(gu), p(act), M, 2 * I, H, st))
-    add("gate|up wgrad (TN, contraction 8192 tokens) N9728 K896", 2.0 * M * 2 * I * H,
+    add("gate|up wgrad, chip-filling plan (TN 128x128 balanced, contraction 8192 tokens) N9728 K896", 2.0 * M * 2 * I * H,
         lambda: lib.slam_op_gemm_tn(p(dgu), p(x), p(dw_gu), 0, M, 2 * I, H, p(ws), st))
+
+    def as_in_step(fn):  # the plan the step uses on its weight-gradient stream: 256x224 tiles, one block per tile, no K-split
+        def run():
+            fn()
+        return run
+    for k, v in ((b"gemm_tn224", 2), (b"gemm_tn224_max_split", 1)):
+        assert lib.slam_set_option(None, k, v) == 0
+    try:
+        add("gate|up wgrad AS LAUNCHED IN THE STEP (TN 256x224 8-phase, 152 one-per-CU blocks, no K-split) - largest launch family by time",
+            2.0 * M * 2 * I * H, as_in_step(lambda: lib.slam_op_gemm_tn(p(dgu), p(x), p(dw_gu), 0, M, 2 * I, H, p(ws), st)))
+        add("down wgrad AS LAUNCHED IN THE STEP (TN 256x224 8-phase, 76 blocks)", 2.0 * M * I * H,
+            as_in_step(lambda: lib.slam_op_gemm_tn(p(y), p(x2), p(dw_d), 0, M, H, I, p(ws), st)))
+    finally:
+        lib.slam_set_option(None, b"gemm_tn224", 1)
+        lib.slam_set_option(None, b"gemm_tn224_max_split", 16)
     add("gate|up dgrad (NT) M8192 N896 K9728", 2.0 * M * 2 * I * H,
         lambda: lib.slam_op_gemm_nt(p(dgu), p(wgut), p(y), None, None, M, H, 2 * I, 1, st))
     add("down fwd + residual (NT) M8192 N896 K4864", 2.0 * M * I * H,
         lambda: lib.slam_op_gemm_nt(p(x2), p(wd), p(y), None, p(x), M, H, I, 1, st))
     add("down dgrad + fused SwiGLU backward (NT 256x256) M8192 N4864 K896", 2.0 * M * I * H,
         lambda: lib.slam_op_gemm_nt_dswiglu(p(y), p(wdt), p(gu), M, I, H, st))
-    add("down wgrad (TN) N896 K4864", 2.0 * M * I * H,
+    add("down wgrad, chip-filling plan (TN 128x128 balanced) N896 K4864", 2.0 * M * I * H,
         lambda: lib.slam_op_gemm_tn(p(y), p(x2), p(dw_d), 0, M, H, I, p(ws), st))
     # attention at the bench shape: 8 sequences x 1024 tokens, 14 / 2 heads of 64; causal-exact flops
     nH, nKV, hd = 14, 2, 64
