@@ -479,6 +479,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     if (h) { h->attn_tune = t; h->have_fwd = false; } else attn_set_default_tune(t);
     return SLAM_OK;
   }
+  if (!strcmp(key, "main_prio")) { norm_set_prio((int)value); return SLAM_OK; }  // process-wide: norm kernels at wave priority 3
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
