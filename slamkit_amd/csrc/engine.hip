@@ -59,7 +59,7 @@ struct SlamEngine {
   int64_t max_tokens = 0;
   std::vector<bf16_t*> hs;  // L+1 residual streams
   std::vector<LayerAct> la;
-  bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dh_b, *dx, *dact, *dqkv, *d_o;
+  bf16_t *hf, *logits, *dlogits, *onehot, *dh_a, *dx, *dact, *dqkv, *d_o;
   int* embed_ws = nullptr;
   const uint8_t* logit_mask = nullptr;  // optional [vpad] bytes: non-zero = column excluded from the softmax
 
@@ -88,6 +88,7 @@ struct SlamEngine {
   // occupy. hipExtStreamCreateWithCUMask makes a BLOCKING stream: it synchronises implicitly with the NULL stream, so the
   // caller must then run the step on a non-default stream (the trainer and bench.py do when the option is set).
   int wside_cus = 0, wside_cus_applied = 0;
+  int wgrad_forks = 4;  // main -> side hand-overs per layer (4, 2 or 1)
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
@@ -186,7 +187,6 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   else { e->onehot = nullptr; e->embed_ws = c.take<int>(embed_bwd_workspace_ints((int)M, e->vpad)); }
   e->row_loss = c.take<float>(M);
   e->dh_a = c.take<bf16_t>(M * H);
-  e->dh_b = c.take<bf16_t>(M * H);
   e->dx = c.take<bf16_t>(M * H);
   e->dact = c.take<bf16_t>(M * I);
   e->dqkv = c.take<bf16_t>(M * e->QKV);
@@ -240,15 +240,26 @@ void add_tensor(SlamEngine* e, const std::string& name, int64_t& off, int64_t ro
     }                                                                                \
   } while (0)
 
+// Flags of the events that only order the engine's streams among themselves. Without hipEventDisableSystemFence every
+// hipEventRecord carries a SYSTEM-scope release - cache write-back and invalidation in the middle of the backward, seven
+// times per layer; nothing on the host reads device memory through these events (SLAM_EVENT_SYSTEM_FENCE=1 restores it).
+static unsigned sync_event_flags() {
+  static const unsigned f = [] {
+    const char* e = getenv("SLAM_EVENT_SYSTEM_FENCE");
+    return (unsigned)hipEventDisableTiming | ((e && e[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+  }();
+  return f;
+}
+
 int ensure_side(SlamEngine* h) {
   if (h->side) return 0;
   hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if (e != hipSuccess) return (int)e;
-  e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  e = hipEventCreateWithFlags(&h->ev_fork, sync_event_flags());
   if (e != hipSuccess) return (int)e;
   h->ev_chunk.resize(h->d.n_layers + 2);
   for (auto& ev : h->ev_chunk) {
-    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    e = hipEventCreateWithFlags(&ev, sync_event_flags());
     if (e != hipSuccess) return (int)e;
   }
   return 0;
@@ -274,7 +285,7 @@ int ensure_wside(SlamEngine* h) {
   if (h->ev_w.empty()) {
     h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
     for (auto& ev : h->ev_w) {
-      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      e = hipEventCreateWithFlags(&ev, sync_event_flags());
       if (e != hipSuccess) return (int)e;
     }
   }
@@ -483,6 +494,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
+  if (!strcmp(key, "bwd_wgrad_forks") && h) { h->wgrad_forks = (int)value; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -597,8 +609,15 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->overwrite_next = false;
 
   // weight-gradient launches: on the main stream, or (bwd_wgrad_stream) on the side stream `ws` behind an event that the
-  // main stream records once their operands exist. slot = (layer index, or L for the head / embedding) * 8 + k:
-  // k 0..3 main->side "operands ready" (wd, wgu, wo, wqkv), k 4..6 side->main "done reading" (dh, dh2, dqkv)
+  // main stream records once their operands exist. Every cross-stream edge costs the recording AND the waiting stream a
+  // barrier packet (~6 us of queue bubble each, measured in the kernel trace), so the schedule keeps them few:
+  //  * no side -> main edges at all: every gradient a weight-gradient GEMM reads lives in a buffer nothing overwrites
+  //    until the next forward - the gradient of hs[l] goes into layer l's (dead) hmid buffer, the gradient of hmid[l]
+  //    into the (dead) hs[l+1] buffer, d(qkv) of layer l into layer l+1's (dead) qkv buffer; all three are buffers only
+  //    main-stream kernels read, and only earlier in this backward;
+  //  * main -> side edges are batched: the GEMMs are queued in launch order and handed over `bwd_wgrad_forks` times per
+  //    layer (4: each as soon as its operands exist; 2: after the down-proj and the o-proj operands; 1: once per layer).
+  // The launch ORDER on the side stream is the same for every setting, so the gradients are bit-identical across them.
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
   GemmTuneScope tune_scope(&h->gemm_tune);
@@ -608,21 +627,38 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     ~SharedGuard() { t->shared = 0; }
   } shared_guard(&h->gemm_tune, two ? 1 : 0);
   hipStream_t ws = two ? h->wside : st;
-  auto ev = [&](int layer, int k) { return h->ev_w[(size_t)layer * 8 + k]; };
-  auto fork = [&](int layer, int k) -> int {  // side stream continues after everything enqueued on main so far
+  int ev_used = 0;
+  auto fork = [&]() -> int {  // side stream continues after everything enqueued on main so far
     if (!two) return 0;
-    hipError_t e = hipEventRecord(ev(layer, k), st);
-    if (e != hipSuccess) return (int)e;
-    return (int)hipStreamWaitEvent(ws, ev(layer, k), 0);
+    if ((size_t)ev_used >= h->ev_w.size()) return SLAM_ESTATE;
+    hipEvent_t e = h->ev_w[ev_used++];
+    hipError_t r = hipEventRecord(e, st);
+    if (r != hipSuccess) return (int)r;
+    return (int)hipStreamWaitEvent(ws, e, 0);
   };
-  auto mark = [&](int layer, int k) -> int { return two ? (int)hipEventRecord(ev(layer, k), ws) : 0; };
-  auto wait_side = [&](int layer, int k) -> int { return two ? (int)hipStreamWaitEvent(st, ev(layer, k), 0) : 0; };
+  struct WGrad { const bf16_t *a, *b; float* g; int n, k; };
+  WGrad pend[8];
+  int npend = 0;
+  auto flush = [&]() -> int {
+    if (!npend) return 0;
+    int r = fork();
+    for (int i = 0; i < npend && !r; ++i)
+      r = gemm_tn(pend[i].a, pend[i].b, pend[i].g, acc, M, pend[i].n, pend[i].k, pend[i].n, pend[i].k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
+    npend = 0;
+    return r;
+  };
+  const int forks = !two ? 4 : (h->wgrad_forks == 1 || h->wgrad_forks == 2) ? h->wgrad_forks : 4;
+  // queue dW = a^T b; `point` 0..3 = wd, wgu, wo, wqkv of a layer
+  auto wgrad = [&](const bf16_t* a, const bf16_t* b, float* g, int n, int k, int point) -> int {
+    pend[npend++] = WGrad{a, b, g, n, k};
+    if (forks == 4 || npend == 8 || (forks == 2 && (point == 0 || point == 2)) || (forks == 1 && point == 0)) return flush();
+    return 0;
+  };
 
-  CK(fork(L, 0));
-  CK(gemm_tn(h->dlogits, h->hf, G + h->off_embed, acc, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
+  CK(wgrad(h->dlogits, h->hf, G + h->off_embed, VP, H, 0));
+  CK(flush());
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
-  bf16_t* dh = h->dh_a;   // grad wrt hs[l+1]
-  bf16_t* dh2 = h->dh_b;  // grad wrt hmid[l]
+  bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
   CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
@@ -631,35 +667,28 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   for (int l = L - 1; l >= 0; --l) {
     const LayerOff& o = h->lo[l];
     LayerAct& a = h->la[l];
+    bf16_t* dh2 = h->hs[l + 1];                              // grad wrt hmid[l]: hs[l+1] was last read by the norm backward above it
+    bf16_t* dqkv = l + 1 < L ? h->la[l + 1].qkv : h->dqkv;   // layer l+1's q|k|v were last read by its attention backward
     // MLP
-    CK(fork(l, 0));
-    CK(gemm_tn(dh, a.act, G + o.wd, acc, M, H, I, H, I, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
-    CK(mark(l, 4));  // dh has been read by the wgrad
+    CK(wgrad(dh, a.act, G + o.wd, H, I, 0));
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
     } else {
       CK(dgrad(dh, o.wd, h->dact, H, I));
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
-    CK(fork(l, 1));
-    CK(gemm_tn(a.gu, a.x2, G + o.wgu, acc, M, 2 * I, H, 2 * I, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
+    CK(wgrad(a.gu, a.x2, G + o.wgu, 2 * I, H, 1));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
-    if (l + 1 < L) CK(wait_side(l + 1, 5));  // the previous layer's wo wgrad still reads dh2
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(fork(l, 2));
-    CK(gemm_tn(dh2, a.o, G + o.wo, acc, M, H, HD, H, HD, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
-    CK(mark(l, 5));
+    CK(wgrad(dh2, a.o, G + o.wo, H, HD, 2));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
-    if (l + 1 < L) CK(wait_side(l + 1, 6));  // the previous layer's wqkv wgrad still reads dqkv
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, h->dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
+    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
-    CK(colsum_bf16(h->dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(fork(l, 3));
-    CK(gemm_tn(h->dqkv, a.x1, G + o.wqkv, acc, M, h->QKV, H, h->QKV, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
-    CK(mark(l, 6));
-    CK(dgrad(h->dqkv, o.wqkv, h->dx, h->QKV, H));
-    CK(wait_side(l, 4));  // this layer's wd wgrad still reads dh
+    CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
+    CK(wgrad(dqkv, a.x1, G + o.wqkv, h->QKV, H, 3));
+    CK(dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
+    dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
     // bucket boundaries: every `bl` layers from the top, and after each of the last two layers so that the
     // final all-reduce (exposed behind the end of backward) only carries layer 0 + the embedding
@@ -676,7 +705,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     if (boundary) {
       // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
       // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
-      CK(fork(l, 7));
+      CK(flush());
+      CK(fork());
       h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
       h->bucket_stream = nullptr;
@@ -686,15 +716,20 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
   // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
   // (on the wgrad stream: ordered after the head's contribution to the same rows)
-  CK(fork(L, 1));
+  CK(flush());
+  CK(fork());
   if (VP == VPAD_SMALL) {
     CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
     CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
   } else {
     CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
   }
-  CK(mark(L, 4));
-  CK(wait_side(L, 4));  // join: everything after slam_backward on `stream` sees complete gradients
+  if (two) {  // join: everything after slam_backward on `stream` sees complete gradients
+    if ((size_t)ev_used >= h->ev_w.size()) return h->fail(SLAM_ESTATE, "event pool exhausted");
+    hipEvent_t e = h->ev_w[ev_used++];
+    CK((int)hipEventRecord(e, ws));
+    CK((int)hipStreamWaitEvent(st, e, 0));
+  }
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;
