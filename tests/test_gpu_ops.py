@@ -204,7 +204,7 @@ def test_gemm_tn_224_phase_scheduled(M, N, K):
 
 
 # --------------------------------------------------------------------------------------- RMSNorm
-@pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536)])
+@pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536), (70, 512), (4099, 2048), (8192, 896), (9001, 1536)])
 def test_rmsnorm_fwd_bwd(M, H):
     x, w, dy, dres = rnd(M, H, seed=1), 1 + 0.1 * rnd(H, seed=2), rnd(M, H, seed=3), rnd(M, H, seed=4)
     w = w.to(torch.bfloat16).float()

@@ -18,8 +18,18 @@ for f in sorted(glob.glob(prefix + "*/**/*counter_collection.csv", recursive=Tru
         continue
     # dispatches of the last optimizer step = after the second-to-last adamw dispatch
     ids = sorted({int(r["Dispatch_Id"]) for r in rows if "adamw" in r["Kernel_Name"]})
-    lo = ids[-2] if len(ids) >= 2 else 0
-    hi = ids[-1] if ids else 1 << 60
+    runs = []  # the optimizer is a run of consecutive AdamW dispatches (one per weight class)
+    for i in ids:
+        if runs and i == runs[-1][1] + 1:
+            runs[-1][1] = i
+        else:
+            runs.append([i, i])
+    lo = runs[-2][1] if len(runs) >= 2 else 0
+    hi = runs[-1][1] if runs else 1 << 60
+    # forward / backward by position relative to the step's loss kernel (the persistent 256x256 launches of the gate|up
+    # forward and of the down-proj dgrad share kernel name and grid)
+    ce = [int(r["Dispatch_Id"]) for r in rows if lo < int(r["Dispatch_Id"]) <= hi and "::ce_" in r["Kernel_Name"].replace("void ", "::")]
+    ce_id = max(ce) if ce else lo
     for r in rows:
         d = int(r["Dispatch_Id"])
         if not (lo < d <= hi):
@@ -27,6 +37,8 @@ for f in sorted(glob.glob(prefix + "*/**/*counter_collection.csv", recursive=Tru
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         if name.startswith("gemm") or name.startswith("reduce"):
             name += f" [{int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))} blocks]"
+        if name.startswith("gemm_nt_256") or name.startswith("gemm_kernel"):
+            name += " fwd" if d < ce_id else " bwd"
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
         "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
