@@ -88,15 +88,6 @@ struct TileOff {
     return (uint32_t)(((size_t)row * ld + c * 8) * sizeof(bf16_t));
   }
 };
-// LDS-DMA with the LDS destination in M0 as an inline-asm register constraint: the compiler materialises each
-// destination with ONE s_mov / s_add into m0 (round 2 saved and restored m0 around every load: 4 SALU per DMA, 32 per
-// forward tile - a wave issues about one instruction per 7 cycles, so scalar bookkeeping is not free).
-SLAM_DEVICE void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
-}
-SLAM_DEVICE void glds4_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
-}
 // one 64x64 tile whose first row is at `tb` (wave-uniform) -> image at LDS address `dst` (this wave's 1 KB slice of each
 // 4 KB half); maxrow >= 63: every row exists (tile-invariant offsets), else rows are clamped to maxrow
 template <bool FULL>

@@ -102,6 +102,14 @@ SLAM_DEVICE void glds16_sv(const void* sbase, uint32_t voff, uint32_t lds_dst) {
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
+// same with the LDS destination as an m0 register constraint: the compiler materialises it with ONE s_mov / s_add
+// instead of saving and restoring m0 around every load
+SLAM_DEVICE void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
+}
+SLAM_DEVICE void glds4_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_dst) : "memory");
+}
 // 4-byte variant: 64 lanes x 4 B -> LDS at M0 + lane*4
 SLAM_DEVICE void glds4(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;

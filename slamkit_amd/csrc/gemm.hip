@@ -681,9 +681,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 template <bool LAST>
 SLAM_DEVICE void wait_ph(int which) {
   // outstanding half-tiles (2 DMAs each) allowed after the wait: 2 in steady state, fewer on the last K-tile
-  if (which == 0) { if (LAST) wait_vmcnt<2>(); else wait_vmcnt<4>(); }
-  else if (which == 1) { if (LAST) wait_vmcnt<0>(); else wait_vmcnt<4>(); }
-  else { if (!LAST) wait_vmcnt<4>(); }
+  // (SLAM_PROBE_VMCNT: a stricter steady-state count for the prefetch-depth probe of tools/probes/depth_probe.sh)
+#ifndef SLAM_PROBE_VMCNT
+#define SLAM_PROBE_VMCNT 4
+#endif
+  if (which == 0) { if (LAST) wait_vmcnt<2>(); else wait_vmcnt<SLAM_PROBE_VMCNT>(); }
+  else if (which == 1) { if (LAST) wait_vmcnt<0>(); else wait_vmcnt<SLAM_PROBE_VMCNT>(); }
+  else { if (!LAST) wait_vmcnt<SLAM_PROBE_VMCNT>(); }
 }
 SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
