@@ -174,6 +174,12 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* ex
  * synchronising: logging only). */
 int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event);
 int slam_param_wait_ms(SlamEngine* h, float* total_ms);
+/* Measurement hook of bench.py's `roofline`: with slam_set_option(h, "time_gateup", 1) every forward brackets the gate|up
+ * projection launch of each layer (the dominant kernel: fused SwiGLU GEMM, 2 M (2I) H flop) with two timing events on the
+ * caller's stream; slam_gateup_launch_ms writes the n_layers durations of the last forward (ms; host-synchronising).
+ * It times the launch where it runs - inside the step, between its neighbours - which is what rocprofv3 reports for the
+ * same launches. No reference counterpart (the reference has no kernel-level timing). */
+int slam_gateup_launch_ms(SlamEngine* h, float* ms_out, int32_t n);
 /* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
  * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
  * joins first. slam_join makes `stream` wait for a pending update before the caller touches the parameter, gradient or

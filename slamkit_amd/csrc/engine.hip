@@ -89,6 +89,8 @@ struct SlamEngine {
   // caller must then run the step on a non-default stream (the trainer and bench.py do when the option is set).
   int wside_cus = 0, wside_cus_applied = 0;
   int wgrad_forks = 4;  // main -> side hand-overs per layer (4, 2 or 1)
+  bool time_gateup = false;        // "time_gateup": timing events around every gate|up projection launch of a forward
+  std::vector<hipEvent_t> tg_ev;   // 2 per layer
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
@@ -99,6 +101,7 @@ struct SlamEngine {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
     for (hipEvent_t e : pw_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : tg_ev) (void)hipEventDestroy(e);
   }
   // parameter ranges another stream is still writing (sharded optimizer: the bf16 parameter all-gather on the
   // communication stream): the next reader waits for the event right before its first read of the range
@@ -495,6 +498,15 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_forks") && h) { h->wgrad_forks = (int)value; return SLAM_OK; }
+  if (!strcmp(key, "time_gateup") && h) {
+    if (value && h->tg_ev.empty()) {
+      h->tg_ev.resize((size_t)2 * h->d.n_layers);
+      for (auto& e : h->tg_ev)
+        if (hipEventCreate(&e) != hipSuccess) { h->tg_ev.clear(); return h->fail(SLAM_ESTATE, "hipEventCreate failed"); }
+    }
+    h->time_gateup = value != 0;
+    return SLAM_OK;
+  }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -550,8 +562,11 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, h->attn_tune, M, nH, nKV, d.head_dim, st));
     CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
     CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
+    const bool timed = h->time_gateup && h->tg_ev.size() == (size_t)(2 * L);
+    if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l], st));
     if (h->fuse_swiglu) {
       CK(gemm_nt_swiglu(a.x2, P + o.wgu, a.gu, a.act, M, 2 * I, H, st));
+      if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l + 1], st));
     } else {
       CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
       CK(swiglu_fwd(a.gu, a.act, M, I, GU_BLK, st));
@@ -904,6 +919,19 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* m_
 int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event) {
   if (!h || !event || offset < 0 || count <= 0 || offset + count > h->n_params) return SLAM_EINVAL;
   h->pwaits.push_back({offset, offset + count, (hipEvent_t)event});
+  return SLAM_OK;
+}
+
+int slam_gateup_launch_ms(SlamEngine* h, float* ms_out, int32_t n) {
+  if (!h || !ms_out || n < h->d.n_layers) return SLAM_EINVAL;
+  if (!h->time_gateup || h->tg_ev.size() != (size_t)(2 * h->d.n_layers)) return h->fail(SLAM_ESTATE, "set the time_gateup option and run a forward first");
+  for (int l = 0; l < h->d.n_layers; ++l) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(h->tg_ev[2 * l + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->tg_ev[2 * l], h->tg_ev[2 * l + 1]);
+    if (e != hipSuccess) return h->fail((int)e, "gate|up timing events are not recorded");
+    ms_out[l] = ms;
+  }
   return SLAM_OK;
 }
 

@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None):
         "slam_adamw_range_bf16": (C.c_int, [vp, i64, i64, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_add_param_wait": (C.c_int, [vp, i64, i64, vp]),
         "slam_param_wait_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "slam_gateup_launch_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int32]),
         "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
@@ -312,6 +313,12 @@ class Engine:
         out = C.c_float(0.0)
         self._ck(self.lib.slam_param_wait_ms(self.h, C.byref(out)))
         return float(out.value)
+
+    def gateup_launch_ms(self, n_layers: int):
+        """Durations (ms) of the gate|up projection launches of the last forward (option time_gateup = 1)."""
+        out = (C.c_float * n_layers)()
+        self._ck(self.lib.slam_gateup_launch_ms(self.h, out, n_layers))
+        return [float(v) for v in out]
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))
