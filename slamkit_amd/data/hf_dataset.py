@@ -302,19 +302,69 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
     return dataset, collator
 
 
-_WORD_RE = None
+_TB_RULES = None
+
+
+def _treebank_rules():
+    """The substitution passes of nltk's NLTKWordTokenizer (nltk/tokenize/destructive.py; the reference constructs it in
+    slamkit/data/hf_dataset.py:128-129 and does not pin an nltk version). nltk is not installed in this image, so the
+    published rule set is restated here: every pass pads what it detaches with spaces, the text is split on whitespace at
+    the end. Order matters and is nltk's: opening quotes, punctuation, brackets, double dashes, closing quotes, clitics."""
+    import re
+    c = re.compile
+    opening = [
+        (c("([\u00ab\u201c\u2018\u201e]|[`]+)"), r" \1 "),
+        (c(r'^"'), "``"),
+        (c(r"(``)"), r" \1 "),
+        (c(r"([ \(\[{<])(\"|'{2})"), r"\1 `` "),
+        (c(r"(?i)(')(?!re|ve|ll|m|t|s|d|n)(\w)\b"), r"\1 \2"),
+    ]
+    punct = [
+        (c("([^\\.])(\\.)([\\]\\)}>\"'\u00bb\u201d\u2019 ]*)\\s*$"), r"\1 \2 \3 "),  # only the text-final period is detached
+        (c(r"([:,])([^\d])"), r" \1 \2"),
+        (c(r"([:,])$"), r" \1 "),
+        (c(r"\.{2,}"), r" \g<0> "),
+        (c(r"[;@#$%&]"), r" \g<0> "),
+        (c(r"([^\.])(\.)([\]\)}>\"']*)\s*$"), r"\1 \2\3 "),
+        (c(r"[?!]"), r" \g<0> "),
+        (c(r"([^'])' "), r"\1 ' "),
+        (c(r"[*]"), r" \g<0> "),
+    ]
+    brackets = (c(r"[\]\[\(\)\{\}\<\>]"), r" \g<0> ")
+    dashes = (c(r"--"), r" -- ")
+    closing = [
+        (c("([\u00bb\u201d\u2019])"), r" \1 "),
+        (c(r"''"), " '' "),
+        (c(r'"'), " '' "),
+        (c(r"([^' ])('[sS]|'[mM]|'[dD]|') "), r"\1 \2 "),
+        (c(r"([^' ])('ll|'LL|'re|'RE|'ve|'VE|n't|N'T) "), r"\1 \2 "),
+    ]
+    clitics = [c(p) for p in (r"(?i)\b(can)(not)\b", r"(?i)\b(d)('ye)\b", r"(?i)\b(gim)(me)\b", r"(?i)\b(gon)(na)\b",
+                              r"(?i)\b(got)(ta)\b", r"(?i)\b(lem)(me)\b", r"(?i)\b(more)('n)\b", r"(?i)\b(wan)(na)(?=\s)",
+                              r"(?i) ('t)(is)\b", r"(?i) ('t)(was)\b")]
+    return opening, punct, brackets, dashes, closing, clitics
 
 
 def word_tokenize(text: str) -> List[str]:
-    """Word splitter for the auto-BLEU repetition filter. The reference uses nltk's NLTKWordTokenizer (Treebank rules,
-    calculation_utils.py:32-35); nltk is not installed here, so its effect on transcript-like text is restated:
-    punctuation becomes its own token, English clitics split off ("don't" -> "do", "n't"; "it's" -> "it", "'s").
-    On punctuation-free ASR transcripts this equals whitespace splitting. Parity unpinned (no nltk to compare with)."""
-    global _WORD_RE
-    import re
-    if _WORD_RE is None:
-        _WORD_RE = re.compile(r"n't\b|'(?:s|m|d|ll|re|ve)\b|\w+?(?=n't\b)|\w+|[^\w\s]", re.IGNORECASE)
-    return _WORD_RE.findall(text)
+    """Word splitter of the auto-BLEU repetition filter: NLTKWordTokenizer().tokenize(text) (calculation_utils.py:32-35),
+    restated from nltk's published rules (see _treebank_rules). Pinned on the known answers of nltk's own documentation
+    (tests/test_data_pipeline.py); no nltk in this image to generate further vectors - said so in DESIGN.md."""
+    global _TB_RULES
+    if _TB_RULES is None:
+        _TB_RULES = _treebank_rules()
+    opening, punct, brackets, dashes, closing, clitics = _TB_RULES
+    for rx, sub in opening:
+        text = rx.sub(sub, text)
+    for rx, sub in punct:
+        text = rx.sub(sub, text)
+    text = brackets[0].sub(brackets[1], text)
+    text = dashes[0].sub(dashes[1], text)
+    text = " " + text + " "
+    for rx, sub in closing:
+        text = rx.sub(sub, text)
+    for rx in clitics:
+        text = rx.sub(r" \1 \2 ", text)
+    return text.split()
 
 
 def calc_ngram(text: str, n: int) -> List[str]:

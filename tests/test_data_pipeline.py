@@ -137,6 +137,14 @@ def test_preference_dataset_repetition_filter(tmp_path):
     from slamkit_amd.data import init_preference_optimization_dataset
     from slamkit_amd.data.hf_dataset import calc_auto_bleu, word_tokenize
     assert word_tokenize("i don't know it's fine") == ["i", "do", "n't", "know", "it", "'s", "fine"]
+    # known answers published in nltk's own documentation for the Treebank rules (the reference's NLTKWordTokenizer,
+    # slamkit/data/hf_dataset.py:128-129): only the TEXT-FINAL period is detached, "$" and "," are, clitics split off
+    assert word_tokenize("Good muffins cost $3.88\nin New York.  Please buy me\ntwo of them.\nThanks.") == [
+        "Good", "muffins", "cost", "$", "3.88", "in", "New", "York.", "Please", "buy", "me", "two", "of", "them.", "Thanks", "."]
+    assert word_tokenize("They'll save and invest more.") == ["They", "'ll", "save", "and", "invest", "more", "."]
+    assert word_tokenize("hi, my name can't hello,") == ["hi", ",", "my", "name", "ca", "n't", "hello", ","]
+    assert word_tokenize('he said, "go." and (left) -- cannot') == [
+        "he", "said", ",", "``", "go.", "''", "and", "(", "left", ")", "--", "can", "not"]
     assert calc_auto_bleu("a b a b c", 2) == 0.5 and calc_auto_bleu("", 2) == 0 and calc_auto_bleu("x", 2) == 0
     rows = [dict(prompt="<Un1>", chosen="<Un2>", rejected="<Un3>", prompt_text="the cat sat", chosen_text="on the mat today", extra=1),
             dict(prompt="<Un4>", chosen="<Un5>", rejected="<Un6>", prompt_text="go go go go", chosen_text="go go go go", extra=2)]
