@@ -443,9 +443,10 @@ class UnitLM(TokenLM):
             if not bool((position_ids == torch.arange(T, dtype=position_ids.dtype)[None]).all()):
                 raise ValueError("position_ids with batch size > 1 must be plain aranges; packed batches are [1, sum T]")
         dev = self.device
-        ids = input_ids.to(dev, torch.int64)
-        lab = labels.to(dev, torch.int64) if labels is not None else None
-        pos = position_ids.to(dev, torch.int64) if position_ids is not None else None
+        nb = not input_ids.is_cuda and input_ids.is_pinned()  # pinned host batches (the trainer's prefetch thread): async H2D
+        ids = input_ids.to(dev, torch.int64, non_blocking=nb)
+        lab = labels.to(dev, torch.int64, non_blocking=nb) if labels is not None else None
+        pos = position_ids.to(dev, torch.int64, non_blocking=nb) if position_ids is not None else None
         # The LDS-DMA wgrad path needs a token count that is a multiple of 64; collated batches have arbitrary lengths.
         # Right-pad the token axis with pad ids / ignored labels (a dummy trailing segment for packed rows): under the
         # causal mask no real token sees the padding, the loss skips it, and the extra logits rows are not returned.

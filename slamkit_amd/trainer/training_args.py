@@ -37,7 +37,7 @@ class SLAMTrainingArguments:
     optim_state_dtype: str = "float32"             # "float32": fp32 master weights + fp32 Adam moments (30 B/param per step); "bfloat16": the recipe's own precision (slam.yaml:9) - bf16 parameters and moments updated in place, no master (16 B/param); "float32_bf16_moments": fp32 master + bf16 moments (22 B/param)
     overwrite_first_grad: bool = True               # first backward of a step stores gradients (no zeroing pass); False = zero in AdamW
     overlap_optimizer: bool = False                # AdamW of the later layers under the next step's first layers (measured neutral: 272.7 vs 273.9 k tok/s)
-    dataloader_num_workers: int = 0
+    dataloader_num_workers: int = 0                # > 0: one background thread collates up to two optimizer steps ahead into pinned host memory (SLAMTrainer._micro_batches)
     min_token_id_count: Optional[int] = None
     max_token_id_count: Optional[int] = None
     # accepted for config compatibility, unused by the engine

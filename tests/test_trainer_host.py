@@ -59,3 +59,34 @@ def test_batch_dealing_round_robin_like_accelerate():
             assert per[r][: full // world] == batches[r:full:world]   # rank r takes r, r+world, ...
         seen = [tuple(b) for p in per for b in p]
         assert set(map(tuple, batches)) <= set(seen)       # nothing dropped
+
+
+def test_collate_prefetch_thread_yields_the_synchronous_stream():
+    """dataloader_num_workers > 0: the background collate thread hands over exactly the micro-batch groups of the
+    synchronous path, in order, also when the consumer stops early, and surfaces a collate error in the consumer."""
+    import types
+    from slamkit_amd.trainer.slam_trainer import SLAMTrainer
+
+    def make(workers, fail_at=None):
+        calls = []
+
+        def collate(idxs):
+            if fail_at is not None and len(calls) == fail_at:
+                raise ValueError("bad row")
+            calls.append(list(idxs))
+            return {"input_ids": torch.tensor(idxs)[None], "labels": torch.tensor(idxs)[None]}
+        return types.SimpleNamespace(args=types.SimpleNamespace(dataloader_num_workers=workers), _collate=collate), calls
+
+    batches = [[4 * i + j for j in range(4)] for i in range(11)]
+    ref = [[m["input_ids"].tolist() for m in g] for g in SLAMTrainer._micro_batches(make(0)[0], batches, 3)]
+    assert [len(g) for g in ref] == [3, 3, 3, 2]
+    got = [[m["input_ids"].tolist() for m in g] for g in SLAMTrainer._micro_batches(make(2)[0], batches, 3)]
+    assert got == ref
+    fake, calls = make(2)
+    it = SLAMTrainer._micro_batches(fake, batches, 3)
+    first = next(it)
+    it.close()  # early stop: the producer thread is released, not left blocked on a full queue
+    assert [m["input_ids"].tolist() for m in first] == ref[0] and len(calls) <= 9
+    import pytest
+    with pytest.raises(ValueError, match="bad row"):
+        list(SLAMTrainer._micro_batches(make(2, fail_at=4)[0], batches, 3))
