@@ -510,7 +510,9 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        # a hung collective must fail the run in minutes, not after RCCL's default 10-minute watchdog per collective
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get("SLAM_NCCL_TIMEOUT_S", "180"))))
         # per-rank RCCL sanity line (stderr: stdout carries the ONE JSON line): a one-element all-reduce over the group
         t = torch.ones(1, device=dev)
         dist.all_reduce(t)
@@ -534,7 +536,9 @@ def main():
                                  overlap_optimizer=os.environ.get("SLAM_OVERLAP_OPTIMIZER", "0") == "1",
                                  overwrite_first_grad=os.environ.get("SLAM_OVERWRITE_FIRST_GRAD", "1") == "1",
                                  ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"),
-                                 ddp_algo=os.environ.get("SLAM_DDP_ALGO", "all_reduce"),
+                                 # N > 1: reduce-scatter + sharded AdamW + parameter all-gather (optimizer time / N, one staging
+                                 # pass); SLAM_DDP_ALGO=all_reduce selects the replicated update
+                                 ddp_algo=os.environ.get("SLAM_DDP_ALGO", "rs_ag" if world > 1 else "all_reduce"),
                                  optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "float32"))
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
@@ -581,13 +585,17 @@ def main():
     # (A stand-alone loop of the same launch reads 137-162 us from run to run: 50 back-to-back launches of the
     # hottest kernel move with the power state of the part, profiles/r3_experiments/README.md.)
     model.engine.set_option("time_gateup", 1)
+    trainer.reducer.time_buckets = world > 1
     in_step_ms = []
     for i in range(3):
         step(a.warmup + a.steps + i)
         in_step_ms += model.engine.gateup_launch_ms(24)
     model.engine.set_option("time_gateup", 0)
+    bucket_ms = trainer.reducer.bucket_ms() if world > 1 else []  # this rank's collectives of the last of those steps
+    trainer.reducer.time_buckets = False
     hbm = hbm_kernel_rates(model, trainer)
-    extras = None if a.no_extras else extra_measurements(model, trainer, rank, dev, a)
+    # the extras are single-GPU context for the headline (GA 16, host boundary, bf16 state); a multi-rank run measures `value` only
+    extras = None if (a.no_extras or world > 1) else extra_measurements(model, trainer, rank, dev, a)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * trained_tokens * a.steps / dt
@@ -606,6 +614,8 @@ def main():
                        "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
                        "ddp_algo": args.ddp_algo if world > 1 else None,
                        "exposed_comm_ms_last_step": round(exposed, 3),
+                       # [what, offset, elements, ms on the communication stream] per bucket, rank 0, one step after the timed region
+                       "bucket_comm_ms": bucket_ms,
                        "exposed_param_gather_ms_total": round(model.engine.param_wait_ms(), 3)},
         }
         roof = dominant_kernel_roofline(model)

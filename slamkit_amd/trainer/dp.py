@@ -64,6 +64,28 @@ class GradBucketReducer:
         self.side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
         # SLAM_DP_FORCE=1: run the collective path even on a single rank (exercises RCCL on a 1-GPU box)
         self.force = os.environ.get("SLAM_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
+        self.time_buckets = False   # bracket every bucket's collective with timing events on the communication stream
+        self._bucket_ev, self._last_bucket_ev = [], []
+
+    def _timed(self, tag, fn):
+        """Run fn() (collectives on the current = communication stream); with time_buckets, between two timing events."""
+        if not self.time_buckets or self.side is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.side)
+        r = fn()
+        e1.record(self.side)
+        self._bucket_ev.append((tag, e0, e1))
+        return r
+
+    def bucket_ms(self):
+        """[(what, offset, count, ms on the communication stream)] of the last finished step (time_buckets = True): the
+        duration of each bucket's collective(s) where they ran - beside backward - not their exposed part."""
+        out = []
+        for (what, off, cnt), e0, e1 in self._last_bucket_ev:
+            e1.synchronize()
+            out.append((what, int(off), int(cnt), round(float(e0.elapsed_time(e1)), 3)))
+        return out
 
     def exposed_ms(self) -> float:
         """Exposed gradient-exchange time of the last finished step (synchronises on its end event); 0 on one rank."""
@@ -88,7 +110,7 @@ class GradBucketReducer:
             ev.record(torch.cuda.ExternalStream(ready_stream, device=self.flat.device) if ready_stream
                       else torch.cuda.current_stream(self.flat.device))
             self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
+            def exchange():
                 if self.comm_dtype is None:
                     self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 else:  # cast -> reduce -> cast back, all ordered on the side stream
@@ -96,6 +118,8 @@ class GradBucketReducer:
                     st.copy_(view)
                     dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
                     view.copy_(st)
+            with torch.cuda.stream(self.side):
+                self._timed(("all_reduce", offset, count), exchange)
         elif self.comm_dtype is None:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -120,6 +144,7 @@ class GradBucketReducer:
             for w in self.pending:
                 w.wait()
         self.pending = []
+        self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
         covered = sorted(self.ranges)
         self.ranges = []
         return covered
@@ -157,14 +182,14 @@ class ShardedGradReducer(GradBucketReducer):
     def tail(self):
         return (self.top, self.n - self.top)
 
-    def _on_side(self, ready_stream, fn):
+    def _on_side(self, ready_stream, fn, tag=None):
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.ExternalStream(ready_stream, device=self.flat.device) if ready_stream
                       else torch.cuda.current_stream(self.flat.device))
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                fn()
+                self._timed(tag, fn) if tag is not None else fn()
         else:
             fn()
 
@@ -189,11 +214,12 @@ class ShardedGradReducer(GradBucketReducer):
         self.active = True
         if offset + count >= self.n and self.top < self.n:  # first range of a backward: the replicated tail
             t0 = self.top
-            self._on_side(ready_stream, lambda: dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group))
+            self._on_side(ready_stream, lambda: dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group),
+                          tag=("all_reduce (replicated tail)", t0, self.n - t0))
         lo = 0 if offset == 0 else min(self.cut_hi, -(-offset // self.align) * self.align)
         if lo < self.cut_hi:
             hi = self.cut_hi
-            self._on_side(ready_stream, lambda: self._reduce_scatter(lo, hi))
+            self._on_side(ready_stream, lambda: self._reduce_scatter(lo, hi), tag=("reduce_scatter", lo, hi - lo))
             self.buckets.append((lo, hi))
             self.cut_hi = lo
 
@@ -213,6 +239,7 @@ class ShardedGradReducer(GradBucketReducer):
         w, r = max(1, self.world), self.rank
         self.owned = [(lo + r * ((hi - lo) // w), (hi - lo) // w) for lo, hi in self.buckets]
         self.last_buckets = list(self.buckets)
+        self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
         self.buckets, self.cut_hi, self.active = [], self.top, False
         covered = sorted(self.ranges)
         self.ranges = []
@@ -230,7 +257,14 @@ class ShardedGradReducer(GradBucketReducer):
             out, inp = self.params[lo:hi], self.params[lo + r * s: lo + (r + 1) * s]
             if self.side is not None:
                 with torch.cuda.stream(self.side):
-                    dist.all_gather_into_tensor(out, inp, group=self.group)
+                    if self.time_buckets:  # reported with the NEXT step's buckets (the gather runs under its forward)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(self.side)
+                        dist.all_gather_into_tensor(out, inp, group=self.group)
+                        e1.record(self.side)
+                        self._bucket_ev.append((("all_gather (parameters)", lo, hi - lo), e0, e1))
+                    else:
+                        dist.all_gather_into_tensor(out, inp, group=self.group)
                     ev = torch.cuda.Event()
                     ev.record(self.side)
                 engine.add_param_wait(lo, hi - lo, ev)

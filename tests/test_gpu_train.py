@@ -274,6 +274,60 @@ def test_fused_adamw_writes_the_transposed_images(osd):
         assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize("osd", ["float32", "bfloat16", "float32_bf16_moments"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_update_over_virtual_ranks_equals_the_replicated_step(world, osd):
+    """The per-rank half of ddp_algo = rs_ag on ONE GPU: `world` virtual ranks take their shards of every bucket in turn
+    (ShardedGradReducer's cut: buckets at multiples of world x chunk, shard r = [lo + r s, lo + (r + 1) s), replicated tail) -
+    chunk sums of the gradient norm, then slam_adamw_range* on the owned ranges, ranks r > 0 included (a 1-rank RCCL run only
+    ever sees r = 0). Gradient norm, parameters, master weights and both moments must equal the replicated clip + AdamW bit
+    for bit, and the transposed images after the refresh the next backward does."""
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    cfg = O.TINY
+    sd = O.init_weights(cfg, seed=4, bias_std=0.02, norm_jitter=0.05)
+    gen = torch.Generator().manual_seed(1)
+    res = []
+    for sharded in (False, True):
+        m = _tiny_model(sd)
+        eng = m.engine
+        n = eng.n_params
+        tr = SLAMTrainer(model=m, args=SLAMTrainingArguments(optim_state_dtype=osd, weight_decay=0.01, max_grad_norm=0.5, logging_steps=0))
+        g2 = torch.Generator().manual_seed(0)
+        norms = []
+        for step in range(2):
+            m.flat_grads.copy_(torch.randn(n, generator=g2) * 1e-2)
+            if not sharded:
+                tr._clip_and_update(1e-3, zero_grad=False)
+            else:
+                chunk, nchunks = eng.grad_chunk_info()
+                align = world * chunk
+                top = (n // align) * align
+                cuts = sorted({0, top} | {(int(top * f) // align) * align for f in (0.21, 0.5, 0.77)})
+                buckets = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+                cs = torch.zeros(nchunks, dtype=torch.float32, device="cuda")
+                owned = {r: [(lo + r * ((hi - lo) // world), (hi - lo) // world) for lo, hi in buckets] for r in range(world)}
+                for r in range(world):
+                    for off, cnt in owned[r]:
+                        eng.grad_sumsq_chunks(off, cnt, cs)
+                if top < n:
+                    eng.grad_sumsq_chunks(top, n - top, cs)
+                eng.grad_norm_from_chunks(cs, 0.5, tr.norm_out)
+                tr.opt_step += 1
+                master = None if tr.state_dtype == torch.bfloat16 else m.flat_master
+                for r in reversed(range(world)):  # any order: the ranges are disjoint
+                    for off, cnt in owned[r] + ([(top, n - top)] if r == 0 and top < n else []):
+                        eng.adamw_range(off, cnt, master, tr.exp_avg, tr.exp_avg_sq, tr.norm_out, 1e-3, tr.args.adam_beta1, tr.args.adam_beta2,
+                                        tr.args.adam_epsilon, tr.args.weight_decay, tr.opt_step, zero_grad=False)
+            norms.append(float(tr.norm_out[0]))
+        eng.refresh_transposed()
+        torch.cuda.synchronize()
+        res.append((norms, m.flat_params.clone(), (m.flat_master if m.flat_master is not None else m.flat_params).clone(),
+                    tr.exp_avg.clone(), tr.exp_avg_sq.clone(), m.flat_params_t.clone()))
+    assert res[0][0] == res[1][0], f"gradient norms differ: {res[0][0]} vs {res[1][0]}"
+    for a, b, name in zip(res[0][1:], res[1][1:], ("params", "master", "exp_avg", "exp_avg_sq", "params_t")):
+        assert torch.equal(a, b), name
+
+
 def test_adamw_bf16_moments_step_vs_oracle():
     """fp32 master + bf16 moments (22 B/param): 5 updates against the oracle's restatement; the master within fp32
     contraction noise, the moments within a bf16 ulp or two."""
