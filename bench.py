@@ -585,13 +585,14 @@ def main():
     # (A stand-alone loop of the same launch reads 137-162 us from run to run: 50 back-to-back launches of the
     # hottest kernel move with the power state of the part, profiles/r3_experiments/README.md.)
     model.engine.set_option("time_gateup", 1)
-    trainer.reducer.time_buckets = world > 1
+    dp_on = world > 1 or trainer.reducer.force  # SLAM_DP_FORCE=1: the collective path on a 1-rank group (tools/dp1_bench.sh)
+    trainer.reducer.time_buckets = dp_on
     in_step_ms = []
     for i in range(3):
         step(a.warmup + a.steps + i)
         in_step_ms += model.engine.gateup_launch_ms(24)
     model.engine.set_option("time_gateup", 0)
-    bucket_ms = trainer.reducer.bucket_ms() if world > 1 else []  # this rank's collectives of the last of those steps
+    bucket_ms = trainer.reducer.bucket_ms() if dp_on else []  # this rank's collectives of the last of those steps
     trainer.reducer.time_buckets = False
     hbm = hbm_kernel_rates(model, trainer)
     # the extras are single-GPU context for the headline (GA 16, host boundary, bf16 state); a multi-rank run measures `value` only
@@ -612,7 +613,7 @@ def main():
                        "final_loss": round(loss, 4),
                        "ms_per_step_median": round(ms_median, 3), "ms_per_step_min": round(per_step[0], 3),
                        "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
-                       "ddp_algo": args.ddp_algo if world > 1 else None,
+                       "ddp_algo": args.ddp_algo if dp_on else None,
                        "exposed_comm_ms_last_step": round(exposed, 3),
                        # [what, offset, elements, ms on the communication stream] per bucket, rank 0, one step after the timed region
                        "bucket_comm_ms": bucket_ms,
