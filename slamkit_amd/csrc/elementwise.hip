@@ -687,13 +687,20 @@ __global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restri
     chunk_sums[first_chunk + kb + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 // out[0] = ||g||, out[1] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 when max_norm<=0)
-__global__ void norm_finish_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) s += (double)part[i];
-  red[threadIdx.x] = s;
+// (one block of 1024: a thread adds its strided elements in four independent fp64 chains - the 43,760 chunk sums of the
+// Slam-358M buffer took 60 us on 256 threads with one dependent chain each; the order is fixed, so every caller - the
+// replicated and the sharded clip - gets the same bits)
+__global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < nb; i += 4 * 1024) {
+    s0 += (double)part[i]; s1 += (double)part[i + 1024]; s2 += (double)part[i + 2048]; s3 += (double)part[i + 3072];
+  }
+  for (; i < nb; i += 1024) s0 += (double)part[i];
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
+  for (int k = 512; k > 0; k >>= 1) {
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
@@ -1052,7 +1059,7 @@ int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* c
   LAUNCH_RET();
 }
 int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st) {
-  norm_finish_kernel<<<1, 256, 0, st>>>(chunk_sums, (int)n_chunks, max_norm, out);
+  norm_finish_kernel<<<1, 1024, 0, st>>>(chunk_sums, (int)n_chunks, max_norm, out);
   LAUNCH_RET();
 }
 int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st) {
