@@ -53,7 +53,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
-      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}};
+      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -90,6 +90,7 @@ struct GemmArgs {
   const float* rope_cos_q;  // tables of the first rope_q_heads heads (queries: pre-scaled, kernels.h rope_table)
   const float* rope_sin_q;
   int rope_q_heads;
+  int stagger_ticks;  // persistent 256 x 256 blocks with one tile fewer than the longest start this many 10-ns ticks late
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -718,6 +719,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     nid = base + idx;
     nid_end = PERSIST ? base + q + (xcd < r ? 1 : 0) : nid + 1;
     nid_step = PERSIST ? (int)(gridDim.x >> 3) : 1;
+    if (PERSIST && p.stagger_ticks > 0) {
+      // The 256 resident blocks run K loop (MFMA-bound) and epilogue (HBM-bound: the fused SwiGLU backward moves 512 KB per
+      // tile) in lockstep. Slots whose tile list is one shorter than the longest have a whole tile period of slack: they
+      // start late, so their epilogues fall under the other blocks' K loops at no cost in makespan.
+      const int mine = (nid_end - nid + nid_step - 1) / nid_step, longest = (nid_end - base + nid_step - 1) / nid_step;
+      if (mine < longest) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+    }
   }
   auto tile_origin = [&](int id, int& r0, int& c0) {
     const int GR = p.group_rows > 0 ? p.group_rows : 1;
@@ -1550,6 +1561,8 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.tiles_c = a.Cn / 256;
   a.group_rows = T().group_rows_256;
   a.nt_store = T().nt_store;
+  a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
+  if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
   const int tiles = a.tiles_r * a.tiles_c;
   if (T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
   else gemm_nt_256_kernel<false><<<tiles, 512, 8 * 128 * 128, st>>>(a);

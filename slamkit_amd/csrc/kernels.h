@@ -18,6 +18,9 @@ struct GemmTune {
   int nt_store = 0;
   int g256 = 1;                 // 256 x 256 NT kernel: 1 = when its fill criterion holds, 0 = never, 2 = whenever the shape allows
   int g256_dswiglu = 1, g256_persist = 1;
+  // late start (10-ns ticks) of the persistent blocks that have a tile of slack (plain / SwiGLU forward; SwiGLU backward):
+  // their store bursts fall under the other blocks' K loops. Same box, interleaved: 24.88 / 24.95 ms vs 25.05 / 25.17 / 25.39
+  int g256_stagger = 1200, g256_stagger_dswiglu = 1200;
   int shared = 0;               // the launches of this call share the GPU with the engine's wgrad stream (set inside slam_backward)
   int nt224 = 1, nt224_min_k = 2048;
   int tn_splits_override = 0, tn_balanced = 1, bal_bg_max_split = 4;
