@@ -110,10 +110,10 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "ms_per_launch": round(ms, 4),
             # L2-miss-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
             # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r3_pmc_step.md, row
-            # `gemm_nt_256_kernel<true> [256 blocks] fwd`: 216.3 MB read + 240.0 MB written), not collected live - counters
+            # `gemm_nt_256_kernel<true> [256 blocks] fwd`: 231.9 MB read + 240.1 MB written), not collected live - counters
             # need rocprofv3 around the process. The write side is exactly algorithmic (159.4 MB gate|up + 79.7 MB act);
-            # the read side is 6.7x the 32 MB of operands: each of the 8 XCD-private L2s streams the 17.4 MB weight.
-            "traffic": 456.3e6, "traffic_source": "recorded: profiles/r3_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/one_step.py, the same persistent launch)",
+            # the read side is 7.2x the 32 MB of operands: each of the 8 XCD-private L2s streams the 17.4 MB weight.
+            "traffic": 472.0e6, "traffic_source": "recorded: profiles/r3_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/one_step.py, the same persistent launch)",
             "algorithmic_bytes": 271.2e6}
 
 

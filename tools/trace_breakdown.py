@@ -1,5 +1,5 @@
 """Step breakdown from a rocprofv3 kernel trace of `bench.py` (one row per launch family, per optimizer step):
-python tools/trace_breakdown.py gpurun_out/s7_prof/r3_kernel_trace.csv profiles/NAME.md "title"
+python tools/trace_breakdown.py gpurun_out/fin_prof/r3_kernel_trace.csv profiles/NAME.md "title" [steps=5] [instrumented steps to skip=3]
 
 Optimizer steps are delimited by the AdamW launch; the steps of the timed region are the LAST `nsteps` steps before the
 probes bench.py runs afterwards (every step before them is identical work). For each step: wall time (first kernel start
@@ -14,6 +14,7 @@ import sys
 
 src, dst, title = sys.argv[1:4]
 nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+skip_last = int(sys.argv[5]) if len(sys.argv) > 5 else 3  # bench.py runs 3 more steps with timing events around the gate|up launches
 rows = []
 for r in csv.DictReader(open(src)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Queue_Id"]),
@@ -49,7 +50,7 @@ for r in rows:
         state = 3
 if cur and state == 3:
     steps.append(cur)
-steps = steps[-nsteps:]
+steps = steps[-(nsteps + skip_last):len(steps) - skip_last] if skip_last else steps[-nsteps:]
 assert steps, "no optimizer steps found"
 
 
@@ -91,7 +92,7 @@ ns = len(steps)
 mean = lambda v: sum(v) / len(v)
 with open(dst, "w") as f:
     f.write(f"# {title}\n\n")
-    f.write(f"Source: `{src}` (rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2`); the last {ns} optimizer steps before the post-run probes.\n\n")
+    f.write(f"Source: `{src}` (rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2`); the {ns} optimizer steps of the timed region (the 3 instrumented steps and the probes that follow are left out).\n\n")
     f.write(f"Step wall time (first kernel start → AdamW end): **{mean(walls)/1e6:.2f} ms** = forward {mean(fw)/1e6:.2f} + backward {mean(bw)/1e6:.2f} + optimizer {mean(op)/1e6:.2f} ms"
             " (rocprofv3 serialises nothing but adds ≈2-3 % to the un-profiled step).\n\n")
     f.write("| stream (HSA queue) | busy ms / step (union of its launch intervals) |\n|---|---|\n")
