@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   if (!bi.valid) return;
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * 128;
-  if (p.prio & 2) __builtin_amdgcn_s_setprio(3);
-  else if (p.prio && p.perm) set_rank_prio(bi.slot, (M + 127) / 128);
+  if (p.prio && p.perm) set_rank_prio(bi.slot, (M + 127) / 128);
   const int qw0 = q0 + wave * 32;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
@@ -421,8 +420,7 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
   if (!bi.valid) return;
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * QT;
-  if (p.prio & 2) __builtin_amdgcn_s_setprio(3);
-  else if (p.prio && p.perm) set_rank_prio(bi.slot, (M + QT - 1) / QT);
+  if (p.prio && p.perm) set_rank_prio(bi.slot, (M + QT - 1) / QT);
   const int qw0 = q0 + wave * WR;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
@@ -650,8 +648,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
   const int kvh = blockIdx.x % p.nKV;
   const int item = p.perm[blockIdx.x / p.nKV];
   if (item < 0) return;  // the item list is sorted by work: invalid (key tile, chunk) candidates sit at its end
-  if (p.prio & 2) __builtin_amdgcn_s_setprio(3);
-  else if (p.prio) set_rank_prio(blockIdx.x / p.nKV, ((M + KT - 1) / KT) * NCH_MAX);
+  if (p.prio) set_rank_prio(blockIdx.x / p.nKV, ((M + KT - 1) / KT) * NCH_MAX);
   const int chunk = item & (NCH_MAX - 1), k0 = (item >> 2) * KT;
   const DkvRange rg = dkv_range(p.seg_end, M, k0, KT, p.nch, chunk);
   const int nq = rg.nq, qa = rg.qa;

@@ -20,8 +20,7 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd,
-                                                          int M, int H, float eps, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+                                                          int M, int H, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -69,8 +68,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                                                           const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_part,
-                                                          int M, int H, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+                                                          int M, int H) {
   __shared__ float red[4][MAXC * 64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -918,18 +916,13 @@ namespace slam {
 
 #define LAUNCH_RET() return (int)hipGetLastError()
 
-// wave priority of the norm kernels (process-wide option "main_prio"): their waves share CUs with resident weight-gradient
-// GEMM blocks in the backward; at priority 3 they win the issue arbitration instead of waiting behind MFMA streams
-static int g_norm_prio = 0;
-void norm_set_prio(int p) { g_norm_prio = p ? 1 : 0; }
-
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st) {
   if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
   switch ((H / 8 + 63) / 64) {
-    case 1: rmsnorm_fwd_kernel<1><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps, g_norm_prio); break;
-    case 2: rmsnorm_fwd_kernel<2><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps, g_norm_prio); break;
-    case 3: rmsnorm_fwd_kernel<3><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps, g_norm_prio); break;
-    default: rmsnorm_fwd_kernel<4><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps, g_norm_prio); break;
+    case 1: rmsnorm_fwd_kernel<1><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    case 2: rmsnorm_fwd_kernel<2><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    case 3: rmsnorm_fwd_kernel<3><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
+    default: rmsnorm_fwd_kernel<4><<<(M + 3) / 4, 256, 0, st>>>(x, w, y, rstd, M, H, eps); break;
   }
   LAUNCH_RET();
 }
@@ -941,10 +934,10 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
   if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   switch ((H / 8 + 63) / 64) {
-    case 1: rmsnorm_bwd_kernel<1><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H, g_norm_prio); break;
-    case 2: rmsnorm_bwd_kernel<2><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H, g_norm_prio); break;
-    case 3: rmsnorm_bwd_kernel<3><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H, g_norm_prio); break;
-    default: rmsnorm_bwd_kernel<4><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H, g_norm_prio); break;
+    case 1: rmsnorm_bwd_kernel<1><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    case 2: rmsnorm_bwd_kernel<2><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    case 3: rmsnorm_bwd_kernel<3><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
+    default: rmsnorm_bwd_kernel<4><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
   }
   if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0);  // dw == null: caller finishes later
   LAUNCH_RET();

@@ -88,7 +88,6 @@ struct SlamEngine {
   // occupy. hipExtStreamCreateWithCUMask makes a BLOCKING stream: it synchronises implicitly with the NULL stream, so the
   // caller must then run the step on a non-default stream (the trainer and bench.py do when the option is set).
   int wside_cus = 0, wside_cus_applied = 0;
-  int wgrad_forks = 4;  // main -> side hand-overs per layer (4, 2 or 1)
   bool time_gateup = false;        // "time_gateup": timing events around every gate|up projection launch of a forward
   std::vector<hipEvent_t> tg_ev;   // 2 per layer
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
@@ -493,11 +492,9 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     if (h) { h->attn_tune = t; h->have_fwd = false; } else attn_set_default_tune(t);
     return SLAM_OK;
   }
-  if (!strcmp(key, "main_prio")) { norm_set_prio((int)value); return SLAM_OK; }  // process-wide: norm kernels at wave priority 3
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
-  if (!strcmp(key, "bwd_wgrad_forks") && h) { h->wgrad_forks = (int)value; return SLAM_OK; }
   if (!strcmp(key, "time_gateup") && h) {
     if (value && h->tg_ev.empty()) {
       h->tg_ev.resize((size_t)2 * h->d.n_layers);
@@ -630,9 +627,9 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   //    until the next forward - the gradient of hs[l] goes into layer l's (dead) hmid buffer, the gradient of hmid[l]
   //    into the (dead) hs[l+1] buffer, d(qkv) of layer l into layer l+1's (dead) qkv buffer; all three are buffers only
   //    main-stream kernels read, and only earlier in this backward;
-  //  * main -> side edges are batched: the GEMMs are queued in launch order and handed over `bwd_wgrad_forks` times per
-  //    layer (4: each as soon as its operands exist; 2: after the down-proj and the o-proj operands; 1: once per layer).
-  // The launch ORDER on the side stream is the same for every setting, so the gradients are bit-identical across them.
+  //  * main -> side: one event per weight-gradient GEMM, recorded as soon as its operands exist. Handing them over in
+  //    batches (two or one event per layer) was measured and is worse (+0.8 / +1.5 ms per Slam-358M step): the side stream
+  //    needs its work as early as it can have it.
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
   GemmTuneScope tune_scope(&h->gemm_tune);
@@ -651,27 +648,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     if (r != hipSuccess) return (int)r;
     return (int)hipStreamWaitEvent(ws, e, 0);
   };
-  struct WGrad { const bf16_t *a, *b; float* g; int n, k; };
-  WGrad pend[8];
-  int npend = 0;
-  auto flush = [&]() -> int {
-    if (!npend) return 0;
-    int r = fork();
-    for (int i = 0; i < npend && !r; ++i)
-      r = gemm_tn(pend[i].a, pend[i].b, pend[i].g, acc, M, pend[i].n, pend[i].k, pend[i].n, pend[i].k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
-    npend = 0;
-    return r;
-  };
-  const int forks = !two ? 4 : (h->wgrad_forks == 1 || h->wgrad_forks == 2) ? h->wgrad_forks : 4;
-  // queue dW = a^T b; `point` 0..3 = wd, wgu, wo, wqkv of a layer
-  auto wgrad = [&](const bf16_t* a, const bf16_t* b, float* g, int n, int k, int point) -> int {
-    pend[npend++] = WGrad{a, b, g, n, k};
-    if (forks == 4 || npend == 8 || (forks == 2 && (point == 0 || point == 2)) || (forks == 1 && point == 0)) return flush();
-    return 0;
+  // dW (+)= a^T b on the weight-gradient stream
+  auto wgrad = [&](const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
+    if (int r = fork()) return r;
+    return gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
   };
 
-  CK(wgrad(h->dlogits, h->hf, G + h->off_embed, VP, H, 0));
-  CK(flush());
+  CK(wgrad(h->dlogits, h->hf, G + h->off_embed, VP, H));
   CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
   CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
@@ -685,23 +668,23 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     bf16_t* dh2 = h->hs[l + 1];                              // grad wrt hmid[l]: hs[l+1] was last read by the norm backward above it
     bf16_t* dqkv = l + 1 < L ? h->la[l + 1].qkv : h->dqkv;   // layer l+1's q|k|v were last read by its attention backward
     // MLP
-    CK(wgrad(dh, a.act, G + o.wd, H, I, 0));
+    CK(wgrad(dh, a.act, G + o.wd, H, I));
     if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
       CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
     } else {
       CK(dgrad(dh, o.wd, h->dact, H, I));
       CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
     }
-    CK(wgrad(a.gu, a.x2, G + o.wgu, 2 * I, H, 1));
+    CK(wgrad(a.gu, a.x2, G + o.wgu, 2 * I, H));
     CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(wgrad(dh2, a.o, G + o.wo, H, HD, 2));
+    CK(wgrad(dh2, a.o, G + o.wo, H, HD));
     CK(dgrad(dh2, o.wo, h->d_o, H, HD));
     CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(wgrad(dqkv, a.x1, G + o.wqkv, h->QKV, H, 3));
+    CK(wgrad(dqkv, a.x1, G + o.wqkv, h->QKV, H));
     CK(dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
     dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
     CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
@@ -720,7 +703,6 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     if (boundary) {
       // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
       // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
-      CK(flush());
       CK(fork());
       h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
@@ -731,7 +713,6 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
   // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
   // (on the wgrad stream: ordered after the head's contribution to the same rows)
-  CK(flush());
   CK(fork());
   if (VP == VPAD_SMALL) {
     CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
