@@ -29,6 +29,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: see slamkit_amd/__init__.py
+os.environ.setdefault("SLAM_ALLOW_FEW_HW_QUEUES", "1")  # a launcher that pinned fewer queues gets a warning and a slower run, not a lost measurement
 
 import torch
 import torch.distributed as dist
