@@ -563,11 +563,11 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l], st));
     if (h->fuse_swiglu) {
       CK(gemm_nt_swiglu(a.x2, P + o.wgu, a.gu, a.act, M, 2 * I, H, st));
-      if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l + 1], st));
     } else {
       CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
       CK(swiglu_fwd(a.gu, a.act, M, I, GU_BLK, st));
     }
+    if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l + 1], st));
     CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
   CK(join_optimizer(h, st));
