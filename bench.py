@@ -586,6 +586,7 @@ def main():
     # (A stand-alone loop of the same launch reads 137-162 us from run to run: 50 back-to-back launches of the
     # hottest kernel move with the power state of the part, profiles/r3_experiments/README.md.)
     model.engine.set_option("time_gateup", 1)
+    model.engine.set_option("time_param_waits", 1)  # rs_ag: the stall of the forward behind the parameter all-gather
     dp_on = world > 1 or trainer.reducer.force  # SLAM_DP_FORCE=1: the collective path on a 1-rank group (tools/dp1_bench.sh)
     trainer.reducer.time_buckets = dp_on
     in_step_ms = []
@@ -593,6 +594,8 @@ def main():
         step(a.warmup + a.steps + i)
         in_step_ms += model.engine.gateup_launch_ms(24)
     model.engine.set_option("time_gateup", 0)
+    param_gather_ms = model.engine.param_wait_ms()
+    model.engine.set_option("time_param_waits", 0)
     bucket_ms = trainer.reducer.bucket_ms() if dp_on else []  # this rank's collectives of the last of those steps
     trainer.reducer.time_buckets = False
     hbm = hbm_kernel_rates(model, trainer)
@@ -618,7 +621,8 @@ def main():
                        "exposed_comm_ms_last_step": round(exposed, 3),
                        # [what, offset, elements, ms on the communication stream] per bucket, rank 0, one step after the timed region
                        "bucket_comm_ms": bucket_ms,
-                       "exposed_param_gather_ms_total": round(model.engine.param_wait_ms(), 3)},
+                       # rs_ag: stall of the forwards behind the parameter all-gather, summed over the 3 instrumented steps
+                       "exposed_param_gather_ms_3_steps": round(param_gather_ms, 3)},
         }
         roof = dominant_kernel_roofline(model)
         ms_in = sum(in_step_ms) / len(in_step_ms)

@@ -171,7 +171,8 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* ex
  * write. The next slam_forward waits for it right before its first read of the range - layer by layer, so the gather of
  * the later layers runs under the first layers' kernels; every other entry point that touches parameters waits for all
  * of them first. slam_param_wait_ms: total stall of the caller's stream in those waits since the last query (host-
- * synchronising: logging only). */
+ * synchronising: logging only; the waits are bracketed by timing events only while slam_set_option(h, "time_param_waits", 1)).
+ * After a ranged update the transposed weight images are rebuilt at the start of the next slam_backward. */
 int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event);
 int slam_param_wait_ms(SlamEngine* h, float* total_ms);
 /* Measurement hook of bench.py's `roofline`: with slam_set_option(h, "time_gateup", 1) every forward brackets the gate|up

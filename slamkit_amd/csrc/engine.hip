@@ -109,6 +109,7 @@ struct SlamEngine {
   std::vector<hipEvent_t> pw_ev;   // timing pairs around the waits (exposed all-gather time), reused step after step
   size_t pw_used = 0;
   bool params_t_dirty = false;     // ranged optimizer updates leave the transposed weight images stale until backward needs them
+  bool time_param_waits = false;   // "time_param_waits": bracket the parameter waits of a forward with timing events (slam_param_wait_ms)
   float* nlse = nullptr;
   float *cosq = nullptr, *sinq = nullptr;  // the query heads' RoPE tables: cos / sin times head_dim^-0.5 * log2(e)
   float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
@@ -310,19 +311,24 @@ int wait_params(SlamEngine* h, int64_t lo, int64_t hi, hipStream_t st) {
   for (size_t i = 0; i < h->pwaits.size();) {
     SlamEngine::ParamWait& w = h->pwaits[i];
     if (w.lo < hi && lo < w.hi) {
-      if (h->pw_used + 2 > h->pw_ev.size()) {
-        for (int k = 0; k < 2; ++k) {
-          hipEvent_t e;
-          hipError_t r = hipEventCreate(&e);
-          if (r != hipSuccess) return (int)r;
-          h->pw_ev.push_back(e);
+      hipError_t r;
+      if (h->time_param_waits) {  // two timing events per wait are two more packets on the caller's stream: measurement runs only
+        if (h->pw_used + 2 > h->pw_ev.size()) {
+          for (int k = 0; k < 2; ++k) {
+            hipEvent_t e;
+            r = hipEventCreate(&e);
+            if (r != hipSuccess) return (int)r;
+            h->pw_ev.push_back(e);
+          }
         }
+        r = hipEventRecord(h->pw_ev[h->pw_used], st);
+        if (r == hipSuccess) r = hipStreamWaitEvent(st, w.ev, 0);
+        if (r == hipSuccess) r = hipEventRecord(h->pw_ev[h->pw_used + 1], st);
+        h->pw_used += 2;
+      } else {
+        r = hipStreamWaitEvent(st, w.ev, 0);
       }
-      hipError_t r = hipEventRecord(h->pw_ev[h->pw_used], st);
-      if (r == hipSuccess) r = hipStreamWaitEvent(st, w.ev, 0);
-      if (r == hipSuccess) r = hipEventRecord(h->pw_ev[h->pw_used + 1], st);
       if (r != hipSuccess) return (int)r;
-      h->pw_used += 2;
       h->pwaits.erase(h->pwaits.begin() + i);
     } else {
       ++i;
@@ -495,6 +501,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
+  if (!strcmp(key, "time_param_waits") && h) { h->time_param_waits = value != 0; return SLAM_OK; }
   if (!strcmp(key, "time_gateup") && h) {
     if (value && h->tg_ev.empty()) {
       h->tg_ev.resize((size_t)2 * h->d.n_layers);

@@ -71,6 +71,11 @@ class SLAMTrainer:
                 raise ValueError("ddp_algo=rs_ag runs the optimizer on shards; overlap_optimizer belongs to the replicated step")
             chunk, n_chunks = model.engine.grad_chunk_info()
             self.reducer = ShardedGradReducer(model.flat_grads, model.flat_params, chunk, comm_dtype=getattr(torch, cd) if cd else None)
+            if args.logging_steps and hasattr(model.engine, "set_option"):
+                try:  # the logged `exposed_param_gather_ms` needs the waits bracketed by timing events (two more packets per wait)
+                    model.engine.set_option("time_param_waits", 1)
+                except Exception:  # noqa: BLE001 - an engine without the option simply reports 0
+                    pass
             self._chunk_sums = torch.zeros(n_chunks, dtype=torch.float32, device=dev)
         else:
             self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)

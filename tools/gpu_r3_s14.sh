@@ -11,7 +11,7 @@ import json
 for n in ("rsag", "allred", "rsag32"):
     try:
         d = json.load(open(f"gpurun_out/dp1_{n}.json")); c = d["config"]
-        print(n, c["ddp_algo"], "exposed", c["exposed_comm_ms_last_step"], "gather", c["exposed_param_gather_ms_total"], c["bucket_comm_ms"])
+        print(n, c["ddp_algo"], "exposed", c["exposed_comm_ms_last_step"], "gather", c["exposed_param_gather_ms_3_steps"], c["bucket_comm_ms"])
     except Exception as e:
         print(n, "FAILED", e)
 P
