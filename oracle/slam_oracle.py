@@ -84,6 +84,43 @@ def _hash_uniform(n: int, seed: int) -> np.ndarray:
     return (2.0 * u - 1.0)
 
 
+def _hash_uniform_t(n: int, seed: int, scale: float, offset: float, dtype) -> torch.Tensor:
+    """offset + scale * _hash_uniform(n, seed) cast to `dtype`, bit for bit, computed with torch (threaded, in place, in
+    chunks): the numpy form above makes ten full-size 64-bit temporaries on one core - 91 s for the 358M parameters of
+    Slam-358M on an 8-core container, most of the wall time of the tests that build a full-size model. int64 arithmetic
+    wraps like uint64; the logical right shifts are arithmetic shifts with the sign extension masked off."""
+    M64 = (1 << 64) - 1
+
+    def i64(v):  # python int (mod 2^64) -> the int64 with the same bits
+        v &= M64
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    c_add = i64(seed * 0x9E3779B97F4A7C15 + 0x9E3779B97F4A7C15)
+    out = torch.empty(n, dtype=dtype)
+    step = 1 << 20
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        x = torch.arange(lo, hi, dtype=torch.int64)
+        x += c_add
+        for sh, mul in ((30, 0xBF58476D1CE4E5B9), (27, 0x94D049BB133111EB)):
+            y = (x >> sh) & ((1 << (64 - sh)) - 1)
+            x ^= y
+            x *= i64(mul)
+        y = (x >> 31) & ((1 << 33) - 1)
+        x ^= y
+        x = (x >> 11) & ((1 << 53) - 1)
+        u = x.to(torch.float64)
+        u /= float(1 << 53)
+        u *= 2.0
+        u -= 1.0            # the uniform(-1, 1) value of _hash_uniform
+        if scale != 1.0:
+            u *= scale
+        if offset != 0.0:
+            u += offset
+        out[lo:hi] = u.to(dtype)
+    return out
+
+
 def init_weights(cfg: OracleConfig, seed: int = 0, std: float = 0.02, bias_std: float = 0.0,
                  norm_jitter: float = 0.0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
     """Synthetic weights (N(0,0.02)-scale matrices, biases 0, norms 1,
@@ -92,12 +129,12 @@ def init_weights(cfg: OracleConfig, seed: int = 0, std: float = 0.02, bias_std: 
     for i, (k, shp) in enumerate(hf_keys(cfg)):
         n = int(np.prod(shp))
         if k.endswith("layernorm.weight") or k.endswith("norm.weight"):
-            w = 1.0 + norm_jitter * _hash_uniform(n, seed * 1000 + i)
+            t = _hash_uniform_t(n, seed * 1000 + i, norm_jitter, 1.0, dtype) if norm_jitter else torch.ones(n, dtype=dtype)
         elif k.endswith(".bias"):
-            w = bias_std * math.sqrt(3.0) * _hash_uniform(n, seed * 1000 + i)
+            t = _hash_uniform_t(n, seed * 1000 + i, bias_std * math.sqrt(3.0), 0.0, dtype) if bias_std else torch.zeros(n, dtype=dtype)
         else:
-            w = std * math.sqrt(3.0) * _hash_uniform(n, seed * 1000 + i)
-        t = torch.from_numpy(np.ascontiguousarray(w.reshape(shp))).to(dtype)
+            t = _hash_uniform_t(n, seed * 1000 + i, std * math.sqrt(3.0), 0.0, dtype)
+        t = t.reshape(shp)
         if k == "lm.model.embed_tokens.weight" and cfg.pad_token_id is not None and cfg.pad_token_id >= 0:
             t[cfg.pad_token_id].zero_()  # nn.Embedding(padding_idx) zero row, hf: modeling_qwen2.py:327
         sd[k] = t
@@ -157,10 +194,21 @@ def attention_mask_bool(B, T, attention_mask=None, position_ids=None, packed=Fal
     return m
 
 
+_FUSED_ATTENTION = True  # False: always the eager expression (equivalence test)
+
+
 def attention(q, k, v, mask, scale, bf16_probs: bool = False):
     """eager_attention_forward with repeat_kv, hf: modeling_qwen2.py:138-172 (softmax in fp32; the probabilities are cast
     to the value dtype before P V - emulated with bf16_probs when the tensors are fp32 stand-ins for bf16 ones)."""
     B, nH, T, hd = q.shape
+    if not bf16_probs and q.dtype == torch.float32 and _FUSED_ATTENTION:
+        # The same function through torch's fused CPU kernel (the call HF's default attn_implementation="sdpa" makes:
+        # modeling_qwen2.py -> sdpa_attention_forward): additive mask with finfo.min like the eager path, fp32 softmax, GQA by
+        # head broadcast. No [B, nH, T, T] tensors: 2-3x less wall time for the full-size models of the GPU parity tests; held to
+        # the eager expression above within 1e-6 (tests/test_oracle_golden.py) and to the reference goldens like before.
+        amask = torch.zeros(mask.shape[0], 1, T, T, dtype=q.dtype).masked_fill_(~mask[:, None], torch.finfo(q.dtype).min)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=amask, scale=scale, enable_gqa=k.shape[1] != nH)
+        return o.transpose(1, 2).contiguous()
     rep = nH // k.shape[1]
     k = k.repeat_interleave(rep, dim=1)
     v = v.repeat_interleave(rep, dim=1)

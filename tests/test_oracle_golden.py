@@ -286,3 +286,37 @@ def test_bf16_emulation_tracks_reference_autocast_per_depth(deep_golden):
     worst_e, worst_r = max(e for _, e, _ in mat), max(r for _, _, r in mat)
     print(f"[anchor] worst matrix-gradient 1 - cos: emulation {worst_e:.2e}, reference {worst_r:.2e}")
     assert 0.5 * worst_r <= worst_e <= 2.0 * worst_r, (worst_e, worst_r)
+
+
+def test_oracle_fast_paths_equal_their_definitions():
+    """Two speed-ups of the oracle itself (it is what the GPU suite spends its minutes on) against the expressions they
+    replace: the threaded counter-hash weight generator is BIT-identical to the numpy definition (fixtures were generated
+    from those weights), and the fused attention call equals the eager softmax(QK^T + mask)V expression within fp32
+    rounding - padded, packed and GQA cases, forward and backward."""
+    import math
+    import numpy as np
+    for n, seed in ((1, 0), (7, 3), (4097, 11), ((1 << 20) + 5, 1004), (2 * (1 << 20) + 1, 7000)):
+        ref = O._hash_uniform(n, seed)
+        for sc, off in ((0.02 * math.sqrt(3.0), 0.0), (0.05, 1.0)):
+            w = (off + sc * ref) if off else sc * ref
+            assert torch.equal(torch.from_numpy(np.ascontiguousarray(w)).to(torch.float32), O._hash_uniform_t(n, seed, sc, off, torch.float32))
+    g = torch.Generator().manual_seed(0)
+    B, nH, nKV, T, hd = 2, 4, 2, 96, 64
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, 70:] = 0                                                     # right-padded row
+    pos = torch.cat([torch.arange(40), torch.arange(56)])[None].expand(B, T)  # two packed segments
+    for mask in (O.attention_mask_bool(B, T, am), O.attention_mask_bool(B, T, None, pos, packed=True)):
+        outs = []
+        for fused in (True, False):
+            q = torch.randn(B, nH, T, hd, generator=g.manual_seed(1)).requires_grad_(True)
+            k = torch.randn(B, nKV, T, hd, generator=g.manual_seed(2)).requires_grad_(True)
+            v = torch.randn(B, nKV, T, hd, generator=g.manual_seed(3)).requires_grad_(True)
+            O._FUSED_ATTENTION = fused
+            try:
+                o = O.attention(q, k, v, mask, hd ** -0.5)
+            finally:
+                O._FUSED_ATTENTION = True
+            (o * torch.randn(o.shape, generator=g.manual_seed(4))).sum().backward()
+            outs.append((o.detach(), q.grad, k.grad, v.grad))
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
