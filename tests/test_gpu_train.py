@@ -130,24 +130,14 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
     between modules) 5.5 % (1.4-2.1 % after smoothing). The engine therefore has to stay inside THAT envelope, which the
     test measures itself on the same token stream: worst single-step deviation <= 1.25 x the bf16-path emulation's (floor
     2 %), smoothed curve (EMA 0.2) within max(1.5 %, 1.25 x the emulation's), and the task is actually being learnt."""
-    from slamkit_amd.data import DataCollatorForLanguageModeling, TokenDataset
-    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments, lr_lambda
-    cfg = O.TINY
-    sd = O.init_weights(cfg, seed=11, bias_std=0.0, norm_jitter=0.0)
-    g = torch.Generator().manual_seed(3)
-    rows = []
-    steps, bs = 200, 4
-    for i in range(steps * bs):
-        n = int(torch.randint(40, 64, (1,), generator=g))
-        start, stride = int(torch.randint(0, 500, (1,), generator=g)), [1, 3, 7][i % 3]
-        ids = [1] + [((start + stride * t) % 500) + 2 for t in range(n)] + [1]
-        rows.append({"input_ids": ids, "attention_mask": [1] * len(ids)})
-    ds = TokenDataset(rows)
-    coll = DataCollatorForLanguageModeling(pad_token_id=0)
-    args = SLAMTrainingArguments(per_device_train_batch_size=bs, gradient_accumulation_steps=1, num_train_epochs=1,
-                                 warmup_steps=5, warmup_ratio=0.0, learning_rate=3e-3, logging_steps=1,
-                                 max_grad_norm=0.5, weight_decay=0.0, seed=13, output_dir="/tmp/unused",
-                                 optim_state_dtype=state_dtype)
+    from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+    from tests import traj_stream as TS
+    sd = O.init_weights(O.TINY, seed=11, bias_std=0.0, norm_jitter=0.0)
+    steps, ds, coll = TS.STEPS, TS.dataset(), TS.collator()
+    args = SLAMTrainingArguments(per_device_train_batch_size=TS.BS, gradient_accumulation_steps=1, num_train_epochs=1,
+                                 warmup_steps=TS.WARMUP, warmup_ratio=0.0, learning_rate=TS.LR, logging_steps=1,
+                                 lr_scheduler_kwargs={"min_lr": TS.MIN_LR}, max_grad_norm=TS.CLIP, weight_decay=0.0,
+                                 seed=TS.SEED, output_dir="/tmp/unused", optim_state_dtype=state_dtype)
     m = _tiny_model(sd)
     tr = SLAMTrainer(model=m, args=args, data_collator=coll, train_dataset=ds)
     assert (m.flat_master is None) == (state_dtype == "bfloat16") and tr.exp_avg.dtype == getattr(torch, state_dtype)
@@ -155,43 +145,11 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
     eng = [r["loss"] for r in state.log_history if "loss" in r]
     assert state.global_step == steps and len(eng) == steps
     bf = state_dtype == "bfloat16"
-    wdt = torch.bfloat16 if bf else torch.float32
-    batches = tr._epoch_batches(0)
-
-    def oracle_loop(bf16_acts):
-        p = {k: v.to(wdt).clone() for k, v in sd.items()}
-        mo = {k: torch.zeros_like(v) for k, v in p.items()}
-        vo = {k: torch.zeros_like(v) for k, v in p.items()}
-        out = []
-        for step in range(steps):
-            mb = coll([ds[i] for i in batches[step]])
-            pw = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
-            l, _, gr = O.forward_loss_grads(cfg, pw, mb["input_ids"], mb["labels"], attention_mask=mb["attention_mask"],
-                                            num_items_in_batch=float((mb["labels"] != -100).sum()), bf16_acts=bf16_acts)
-            out.append(float(l))
-            if bf:  # the reference's gradients live in the parameters' dtype
-                gr = {k: v.to(torch.bfloat16).float() for k, v in gr.items()}
-            _, coef = O.clip_coef(gr, 0.5)
-            lr = args.learning_rate * lr_lambda(args, step, steps)
-            for k in p:
-                if bf:
-                    O.adamw_update_bf16(p[k], (gr[k] * coef).to(torch.bfloat16), mo[k], vo[k], step + 1, lr)
-                else:
-                    O.adamw_update(p[k], gr[k] * coef, mo[k], vo[k], step + 1, lr)
-        return out
-
-    def ema(x, k=0.2):
-        o, a = [], x[0]
-        for v in x:
-            a = (1 - k) * a + k * v
-            o.append(a)
-        return o
-
-    def worst(x, y):
-        return max(abs(u - v) / v for u, v in zip(x, y))
-
-    ref = oracle_loop(False)
-    emu = oracle_loop(True)   # the same loop in the reference's own activation precision: the sensitivity envelope
+    ema, worst = TS.ema, TS.worst
+    # the same loop on the oracle: bf16 state = the recipe's precision; fp32 state = fp32 master weights whose bf16 rounding
+    # the forward / backward computes with (what the engine does)
+    ref = TS.oracle_loop(bf, False, round_weights=not bf)[0]
+    emu = TS.oracle_loop(bf, True, round_weights=not bf)[0]   # the same loop in the reference's own activation precision: the sensitivity envelope
     print("engine", [round(x, 3) for x in eng[::20]])
     print("oracle", [round(x, 3) for x in ref[::20]])
     print("bf16-path emulation", [round(x, 3) for x in emu[::20]])
@@ -204,6 +162,20 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
         assert abs(a - b) <= 0.01 * b + 1e-2, (a, b)
     assert w_eng <= max(0.02, 1.25 * w_emu), (w_eng, w_emu)
     assert s_eng <= max(0.015, 1.25 * s_emu), (s_eng, s_emu)
+    # ---- and against the REAL reference model on the HF / torch step (tests/golden/traj.npz, make_golden_traj.py): the
+    # fp32-state engine against the reference's fp32 leg, the bf16-state engine against its bf16 leg (bf16 parameters, bf16
+    # autocast, bf16 AdamW). The envelope is the oracle emulation's distance from the same fixture curve (the oracle's
+    # fp32 loop itself reproduces the fp32 leg to 0.15 %, tests/test_oracle_golden.py).
+    fx = TS.load_fixture()
+    leg = fx["loss_bf16"] if bf else fx["loss_fp32"]
+    fw_eng, fw_emu = worst(eng, leg), worst(emu, leg)
+    fs_eng, fs_emu = worst(ema(eng), ema(leg)), worst(ema(emu), ema(leg))
+    f60 = worst(eng[:60], leg[:60])
+    print(f"[parity] 200-step curve vs the reference's own {'bf16' if bf else 'fp32'} trajectory: worst single-step deviation engine "
+          f"{fw_eng:.4f} / emulation {fw_emu:.4f}; smoothed engine {fs_eng:.4f} / emulation {fs_emu:.4f}; first 60 steps {f60:.4f}")
+    assert f60 <= max(0.015, 1.25 * worst(emu[:60], leg[:60])), f60
+    assert fw_eng <= max(0.03, 1.5 * fw_emu), (fw_eng, fw_emu)
+    assert fs_eng <= max(0.02, 1.5 * fs_emu), (fs_eng, fs_emu)
 
 
 def test_adamw_bf16_state_step_vs_oracle():

@@ -320,3 +320,48 @@ def test_oracle_fast_paths_equal_their_definitions():
             outs.append((o.detach(), q.grad, k.grad, v.grad))
         for a, b in zip(*outs):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+# ---- the Trainer-level step against the REAL reference model on the HF / torch step (tests/golden/make_golden_traj.py) ----
+def test_step_restatement_reproduces_the_reference_fp32_trajectory():
+    """200 optimizer steps: slamkit.model.UnitLM + torch.optim.AdamW + transformers' cosine_with_min_lr scheduler +
+    clip_grad_norm_(0.5) (the fixture) vs the oracle's own loop (forward_loss_grads, clip_coef, cosine_with_min_lr,
+    adamw_update). Stated tolerance: the learning rates are identical; the curves agree to 1e-4 for the first 60 steps
+    (measured 1.7e-5) and to 5e-3 absolute over all 200 (measured 2.8e-3 = 0.15 %: two fp32 implementations of a run
+    whose loss falls from 6.1 to 1.8 at lr 3e-3 drift apart at that rate); pre-clip gradient norms within 3 %, the norm of
+    every final parameter tensor within 2e-3."""
+    from tests.traj_stream import load_fixture, oracle_loop
+    fx = load_fixture()
+    losses, gns, lrs, p = oracle_loop(False, False)
+    ref = fx["loss_fp32"]
+    assert len(losses) == len(ref) == 200
+    assert np.abs(np.array(lrs) - fx["lr"]).max() <= 1e-12
+    d = np.abs(np.array(losses) - ref)
+    print(f"[parity] step restatement vs reference fp32 trajectory: first 60 steps {d[:60].max():.2e}, all 200 {d.max():.2e}")
+    assert d[:60].max() <= 1e-4, d[:60].max()
+    assert d.max() <= 5e-3, d.max()
+    g = np.abs(np.array(gns) - fx["grad_norm_fp32"]) / fx["grad_norm_fp32"]
+    assert g[:60].max() <= 1e-3 and g.max() <= 3e-2, (g[:60].max(), g.max())
+    for k, n in zip(fx["final_keys"], fx["final_norm_fp32"]):
+        assert abs(float(p[str(k)].norm()) - n) <= 2e-3 * n, (k, float(p[str(k)].norm()), n)
+
+
+def test_bf16_step_emulation_tracks_the_reference_bf16_trajectory():
+    """The recipe's own precision (bf16 parameters, bf16 autocast, bf16 AdamW state: config/model/slam.yaml:9): the
+    reference's bf16 run strays up to 13 % (single step) / 8.9 % (smoothed) from its own fp32 run on this stream - that is
+    the precision gap of the recipe, not an error. The oracle's emulation (bf16 tensors between modules, gradients rounded
+    to bf16, adamw_update_bf16) has to land on the BF16 curve: first 60 steps within 1.5 % (measured 0.5 %), every step
+    within 6 % (3.9 %), smoothed within 3 % (1.7 %) - several times closer to the bf16 leg than the bf16 leg is to fp32 -
+    and its own gap to the fp32 leg has to be of the reference's size (0.5x .. 2x)."""
+    from tests.traj_stream import ema, load_fixture, oracle_loop, worst
+    fx = load_fixture()
+    losses, gns, _, p = oracle_loop(True, True)
+    r16, r32 = fx["loss_bf16"], fx["loss_fp32"]
+    w, s, f60 = worst(losses, r16), worst(ema(losses), ema(r16)), worst(losses[:60], r16[:60])
+    gap_ref, gap_emu = worst(ema(r16), ema(r32)), worst(ema(losses), ema(r32))
+    print(f"[parity] bf16 step emulation vs reference bf16 trajectory: first 60 {f60:.4f}, worst {w:.4f}, smoothed {s:.4f}; "
+          f"smoothed gap to the fp32 leg: reference {gap_ref:.4f}, emulation {gap_emu:.4f}")
+    assert f60 <= 0.015 and w <= 0.06 and s <= 0.03, (f60, w, s)
+    assert 0.5 * gap_ref <= gap_emu <= 2.0 * gap_ref, (gap_ref, gap_emu)
+    for k, n in zip(fx["final_keys"], fx["final_norm_bf16"]):
+        assert abs(float(p[str(k)].float().norm()) - n) <= 0.08 * n, (k, float(p[str(k)].float().norm()), n)
