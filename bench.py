@@ -189,6 +189,33 @@ def kernel_rooflines(model, iters=30, warm=10):
     return rows
 
 
+def in_step_table(fam):
+    """Launch families of the step as they run IN the step (HIP timing events around each launch on its own stream, three
+    optimizer steps after the timed region): launches per step, mean us per launch, ms per step, and for the matmul families
+    the algorithmic flops -> fraction of the dense bf16 peak at that in-step duration. Sorted by ms per step; the first row
+    is the dominant family by time. Durations on the two backward streams overlap, so the column sums exceed the step."""
+    M, H, I, QKV, HD, VP = B * T, 896, 4864, 1152, 896, 512
+    attn = 4.0 * 64 * (T * (T + 1) / 2) * B * 14
+    flops = {"qkv_fwd": 2.0 * M * QKV * H, "o_fwd": 2.0 * M * H * HD, "gateup_fwd": 2.0 * M * 2 * I * H, "down_fwd": 2.0 * M * H * I,
+             "attn_fwd": attn, "attn_bwd": 2.5 * attn, "head_fwd": 2.0 * M * VP * H, "head_dgrad": 2.0 * M * VP * H, "head_wgrad": 2.0 * M * VP * H,
+             "down_dgrad_dswiglu": 2.0 * M * H * I, "gateup_dgrad": 2.0 * M * 2 * I * H, "o_dgrad": 2.0 * M * H * HD, "qkv_dgrad": 2.0 * M * QKV * H,
+             "wd_wgrad": 2.0 * M * H * I, "wgu_wgrad": 2.0 * M * 2 * I * H, "wo_wgrad": 2.0 * M * H * HD, "wqkv_wgrad": 2.0 * M * QKV * H,
+             "embed_wgrad": 2.0 * M * VP * H}
+    side = {"wd_wgrad", "wgu_wgrad", "wo_wgrad", "wqkv_wgrad", "head_wgrad", "embed_wgrad"}
+    rows = []
+    for name, v in fam.items():
+        us = sum(v) / len(v) * 1e3
+        r = {"family": name, "stream": "wgrad side stream" if name in side else "caller's stream", "launches_per_step": round(len(v) / 3, 1),
+             "us_in_step": round(us, 1), "ms_per_step": round(sum(v) / 3, 3)}
+        if name in flops:
+            r["gflop"] = round(flops[name] / 1e9, 1)
+            r["frac_of_peak_in_step"] = round(flops[name] / (us * 1e-6) / PEAK_BF16, 4)
+        rows.append(r)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return {"dominant_by_time": rows[0]["family"] if rows else None, "families": rows,
+            "measured": "HIP timing-event pairs around every launch on its own stream (slam_family_ms), 3 optimizer steps after the timed region"}
+
+
 PEAK_HBM = 8.0e12  # B/s, MI355X_MICROARCH.md (about 6.3e12 reachable by a streaming copy)
 
 
@@ -240,6 +267,11 @@ def hbm_kernel_rates(model, trainer):
         # (the launch includes the transposed-weight-image refresh: + 4 B per matrix element)
         row("adamw_tile_kernel (fp32 master + moments; writes the transposed bf16 images itself)", us, 32 * n,
             "30 B/param AdamW + 2 B/param transposed image")
+    else:
+        us = _time_us(lambda: eng.adamw_step_bf16(trainer.exp_avg, trainer.exp_avg_sq, trainer.norm_out, 0.0, 0.9, 0.999, 1e-8, 0.0, 1000,
+                                                  zero_grad=False), iters=5, warm=2)
+        row("adamw_tile_kernel (bf16 parameters + bf16 moments in place, the recipe's precision; writes the transposed bf16 images itself)",
+            us, 18 * n, "16 B/param AdamW (fp32 grad read, bf16 p/m/v read + written) + 2 B/param transposed image")
     us = _time_us(lambda: eng.grad_norm(0.5, trainer.norm_out), iters=10, warm=2)
     row("sumsq_partial_kernel + norm_finish_kernel (global gradient norm)", us, 4 * n, "4 B/param")
     return out
@@ -289,11 +321,17 @@ def extra_measurements(model, trainer, rank, dev, a):
     dt = time.perf_counter() - t0
     res["host_boundary"] = {"tokens_per_s": round(world * B * T * steps_h / dt, 1), "ms_per_step": round(dt / steps_h * 1e3, 3), "steps": steps_h,
                             "what": "collate on the host + CPU int64 batches through UnitLM.forward (H2D inside the step)"}
+    other = "bfloat16" if trainer.state_dtype == torch.float32 else "float32"
     args2 = SLAMTrainingArguments(per_device_train_batch_size=B, gradient_accumulation_steps=1, learning_rate=1e-3, max_grad_norm=0.5,
-                                  logging_steps=0, optim_state_dtype="bfloat16",
+                                  logging_steps=0, optim_state_dtype=other,
                                   ddp_comm_dtype=os.environ.get("SLAM_DDP_COMM_DTYPE", "bfloat16"))
-    if trainer.state_dtype == torch.float32:
-        del trainer.exp_avg, trainer.exp_avg_sq
+    del trainer.exp_avg, trainer.exp_avg_sq
+    if other == "float32":  # the headline ran in the recipe's precision: give the model an fp32 master copy for this leg
+        model.flat_master = model.flat_params.float()
+        tr2 = SLAMTrainer(model=model, args=args2)
+        res["fp32_master_optimizer"] = dict(run(tr2, 1, max(5, min(a.steps, 20)), 3),
+                                            what="AdamW with fp32 master weights + fp32 moments (30 B/param) instead of the recipe's bf16 state")
+    else:
         tr2 = SLAMTrainer(model=model, args=args2)  # drops the fp32 master: the bf16 parameters become the only copy
         res["recipe_optimizer_bf16_state"] = run(tr2, 1, max(5, min(a.steps, 20)), 3)
     return res
@@ -540,15 +578,23 @@ def main():
                                  # N > 1: reduce-scatter + sharded AdamW + parameter all-gather (optimizer time / N, one staging
                                  # pass); SLAM_DDP_ALGO=all_reduce selects the replicated update
                                  ddp_algo=os.environ.get("SLAM_DDP_ALGO", "rs_ag" if world > 1 else "all_reduce"),
-                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "float32"))
+                                 # the recipe's own optimizer precision (/root/reference config/model/slam.yaml:9 torch_dtype bfloat16:
+                                 # the HF Trainer builds AdamW on bf16 parameters, so the moments are bf16 too); the fp32-master
+                                 # variant is measured after the timed region (`extras.fp32_master_optimizer`)
+                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16"))
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
     batches = [[synth_batch(rank, i * a.grad_accum + j, dev) for j in range(a.grad_accum)] for i in range(nb)]
     n_items = float(B * T * a.grad_accum)   # HF num_items_in_batch counts unshifted labels != -100
     trained_tokens = B * T * a.grad_accum  # SLAMTrainer.get_num_tokens definition: labels != -100 (slam_trainer.py:59-65)
 
+    # the token-count all-reduce of step k + 1 is posted (host-side gloo, asynchronous) before step k is enqueued, as
+    # SLAMTrainer.train() does with its collate-ahead batches: every step still has its own collective
+    ahead = {"h": trainer.post_counts(n_items, n_items)}
+
     def step(i):
-        trainer.optimizer_step(batches[i % nb], 1e-3, counts=(n_items, n_items))
+        h, ahead["h"] = ahead["h"], trainer.post_counts(n_items, n_items)
+        trainer.optimizer_step(batches[i % nb], 1e-3, counts=(n_items, n_items), counts_handle=h)
 
     def fence():
         if world > 1:
@@ -594,6 +640,15 @@ def main():
         step(a.warmup + a.steps + i)
         in_step_ms += model.engine.gateup_launch_ms(24)
     model.engine.set_option("time_gateup", 0)
+    # ... and three more with a timing-event pair around EVERY launch family, on the stream each launch goes to
+    # (slam_family_ms): the in-step duration of the dgrad chain and of the weight-gradient GEMMs on the side stream
+    model.engine.set_option("time_families", 1)
+    fam = {}
+    for i in range(3):
+        step(a.warmup + a.steps + 3 + i)
+        for name, ms_ in model.engine.family_ms():
+            fam.setdefault(name, []).append(ms_)
+    model.engine.set_option("time_families", 0)
     param_gather_ms = model.engine.param_wait_ms()
     model.engine.set_option("time_param_waits", 0)
     bucket_ms = trainer.reducer.bucket_ms() if dp_on else []  # this rank's collectives of the last of those steps
@@ -613,7 +668,8 @@ def main():
                        "model": "Slam-358M", "global_batch": world * B * a.grad_accum, "micro_batch": B, "seq_len": T,
                        "grad_accum": a.grad_accum, "parallelism": f"dp{world}",
                        "optimizer": ("AdamW fp32 master+moments" if args.optim_state_dtype == "float32" else
-                                     "AdamW bf16 parameters+moments (the recipe's precision)") + ", clip 0.5",
+                                     "AdamW on bf16 parameters with bf16 moments - the recipe's own precision (reference config/model/slam.yaml:9); "
+                                     "fp32-master variant in extras") + ", clip 0.5",
                        "final_loss": round(loss, 4),
                        "ms_per_step_median": round(ms_median, 3), "ms_per_step_min": round(per_step[0], 3),
                        "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
@@ -638,6 +694,7 @@ def main():
         roof["step_frac"] = round(value / world * FLOP_PER_TOKEN / PEAK_BF16, 4)
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
         roof["kernels"] = kernel_rooflines(model)
+        roof["in_step"] = in_step_table(fam)
         out["roofline"] = roof
         out["hbm_kernels"] = hbm
         if extras is not None:

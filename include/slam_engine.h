@@ -181,6 +181,22 @@ int slam_param_wait_ms(SlamEngine* h, float* total_ms);
  * It times the launch where it runs - inside the step, between its neighbours - which is what rocprofv3 reports for the
  * same launches. No reference counterpart (the reference has no kernel-level timing). */
 int slam_gateup_launch_ms(SlamEngine* h, float* ms_out, int32_t n);
+/* The same hook for EVERY launch family of the step: with slam_set_option(h, "time_families", 1) slam_forward and
+ * slam_backward bracket each launch (projection / attention / norm / loss kernels, the dgrad chain, and the weight-gradient
+ * GEMMs on the engine's side stream(s)) with a timing-event pair on the stream the launch goes to. slam_family_ms writes up
+ * to `capacity` (family id, ms) records of the last forward + backward in launch order and their number (host-synchronising);
+ * slam_family_name maps an id to its name ("gateup_fwd", "wgu_wgrad", ... ; NULL past the last id). A record is the time
+ * between the launch's stream reaching it and the launch completing - beside whatever the other stream runs - i.e. the
+ * in-step duration a kernel trace reports, not a stand-alone time. Two more packets per launch: measurement steps only.
+ * No reference counterpart. */
+int slam_family_ms(SlamEngine* h, int32_t* family_out, float* ms_out, int32_t capacity, int32_t* count_out);
+const char* slam_family_name(int32_t family);
+/* Data-parallel gradient exchange in bf16 (replaces the dtype conversion torch DDP never needs because the reference's
+ * gradients ARE bf16: /root/reference config/model/slam.yaml:9 with config/training_args/default.yaml:18): pack
+ * grads[offset, offset + count) (fp32) into a bf16 communication buffer (round-to-nearest-even) / widen a reduced bf16 range
+ * back into the fp32 gradient buffer. offset and count are multiples of 4; dst / src point at the range's first element. */
+int slam_pack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, void* dst_bf16, slam_stream_t stream);
+int slam_unpack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, const void* src_bf16, slam_stream_t stream);
 /* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
  * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
  * joins first. slam_join makes `stream` wait for a pending update before the caller touches the parameter, gradient or
@@ -197,7 +213,9 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
  * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "bwd_wgrad_stream" (default
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
- * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
+ * reported bucket range, and the end of the call). "bwd_wgrad_small_stream" = 1: the short weight-gradient launches (Wo,
+ * Wqkv, head, embedding) get a third engine-owned stream with their own slab workspace. "gemm_256_shared_blocks" = N: grid of
+ * the persistent 256 x 256 launches inside slam_backward (0 = one block per CU). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
  * "gemm_256_dswiglu", "gemm_256_persist", "gemm_tn224", "gemm_tn_balanced", "gemm_group_rows" select kernels. */
 int slam_set_option(SlamEngine* h, const char* key, int64_t value);
 

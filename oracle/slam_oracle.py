@@ -14,8 +14,14 @@ over a locally built Qwen2Config, the real UnitTokeniser / chunk_texts / HF coll
 authoring container and stores inputs + outputs under tests/golden/; tests/test_oracle_golden.py
 checks this restatement against those vectors (fp32: logits <= 1e-5 abs, loss <= 1e-6, grads <= 1e-5
 rel), and against the reference's own known-answer pair example_data/{features,tokens}.jsonl.
-The Trainer-level step (SLAMTrainer cannot be constructed on transformers 5.x, slam_trainer.py:50)
-and TRL's DPO loss are restated from their definitions - "parity unpinned" for those two only.
+The optimizer step (clip_coef, cosine_with_min_lr, adamw_update / adamw_update_bf16 around forward_loss_grads) is
+pinned as a LOOP since round 4: tests/golden/make_golden_traj.py runs the real slamkit.model.UnitLM under
+torch.optim.AdamW + transformers.get_scheduler("cosine_with_min_lr") + clip_grad_norm_ for 200 steps in fp32 and in the
+recipe's bf16 precision (traj.npz); this restatement reproduces the fp32 curve to 2e-5 over the first 60 steps and
+0.15 % over all 200, and its bf16 emulation lands on the reference's bf16 curve (tests/test_oracle_golden.py).
+Still "parity unpinned": the HF `Trainer` plumbing around that loop (SLAMTrainer cannot be constructed on transformers
+5.x, slam_trainer.py:50 - gradient-accumulation bookkeeping and `num_items_in_batch` gathering are restated from
+trainer.py) and TRL's DPO loss (TRL absent).
 """
 from __future__ import annotations
 

@@ -90,11 +90,24 @@ struct SlamEngine {
   int wside_cus = 0, wside_cus_applied = 0;
   bool time_gateup = false;        // "time_gateup": timing events around every gate|up projection launch of a forward
   std::vector<hipEvent_t> tg_ev;   // 2 per layer
+  // "time_families": timing-event pairs around the launches of every family of slam_forward / slam_backward (slam_family_ms),
+  // each on the stream the launch goes to - the in-step duration of a launch between its real neighbours, what a kernel
+  // trace shows for it. Two more packets per launch: measurement steps only.
+  bool time_families = false;
+  std::vector<hipEvent_t> fam_ev;                 // pool, reused step after step
+  std::vector<std::pair<int, size_t>> fam_marks;  // (family id, index of the pair's first event)
+  // "bwd_wgrad_small_stream": the short weight-gradient launches (Wo, Wqkv, head, embedding: the balanced 128 x 128 kernel and
+  // its slab reduces) get a stream of their own, so that they are not queued behind the two long 256 x 224 launches of
+  // their layer; the slab workspace belongs to that stream alone (the long launches run unsplit: no slabs)
+  int wgrad_small_stream = 0;
+  hipStream_t wside2 = nullptr;
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
   ~SlamEngine() {
     if (wside) { (void)hipStreamSynchronize(wside); (void)hipStreamDestroy(wside); }
+    if (wside2) { (void)hipStreamSynchronize(wside2); (void)hipStreamDestroy(wside2); }
+    for (hipEvent_t e : fam_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_w) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -112,7 +125,7 @@ struct SlamEngine {
   bool time_param_waits = false;   // "time_param_waits": bracket the parameter waits of a forward with timing events (slam_param_wait_ms)
   float* nlse = nullptr;
   float *cosq = nullptr, *sinq = nullptr;  // the query heads' RoPE tables: cos / sin times head_dim^-0.5 * log2(e)
-  float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
+  float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *gemm_ws2, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
   size_t gemm_ws_bytes = 0;
@@ -206,6 +219,7 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->attn_plan_buf = c.take<int>(attn_plan_ints((int)M));
   e->gemm_ws_bytes = max_gemm_ws(e, (int)M);
   e->gemm_ws = c.take<float>(e->gemm_ws_bytes / sizeof(float));
+  e->gemm_ws2 = c.take<float>(e->gemm_ws_bytes / sizeof(float));  // "bwd_wgrad_small_stream": the short launches' own slabs
   size_t part = (size_t)rmsnorm_bwd_blocks((int)M) * H;
   size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
   if (part2 > part) part = part2;
@@ -254,6 +268,41 @@ static unsigned sync_event_flags() {
   return f;
 }
 
+// launch families of the step (slam_family_name); ids are stable within a library build only
+enum Fam {
+  F_QKV_FWD, F_ATTN_FWD, F_O_FWD, F_GATEUP_FWD, F_DOWN_FWD, F_NORM_FWD, F_HEAD_FWD, F_LOSS,
+  F_DOWN_DGRAD, F_GATEUP_DGRAD, F_O_DGRAD, F_QKV_DGRAD, F_ATTN_BWD, F_NORM_BWD, F_HEAD_DGRAD,
+  F_WD_WGRAD, F_WGU_WGRAD, F_WO_WGRAD, F_WQKV_WGRAD, F_HEAD_WGRAD, F_EMBED_WGRAD, F_COUNT
+};
+const char* const kFamName[F_COUNT] = {
+    "qkv_fwd", "attn_fwd", "o_fwd", "gateup_fwd", "down_fwd", "norm_fwd", "head_fwd", "loss",
+    "down_dgrad_dswiglu", "gateup_dgrad", "o_dgrad", "qkv_dgrad", "attn_bwd", "norm_bwd", "head_dgrad",
+    "wd_wgrad", "wgu_wgrad", "wo_wgrad", "wqkv_wgrad", "head_wgrad", "embed_wgrad"};
+
+// first event of a timing pair around a launch of family `fam` on `st`; returns the pair's slot, -1 when timing is off or failed
+int fam_begin(SlamEngine* h, int fam, hipStream_t st) {
+  if (!h->time_families) return -1;
+  const size_t at = h->fam_marks.size() * 2;
+  while (h->fam_ev.size() < at + 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    h->fam_ev.push_back(e);
+  }
+  if (hipEventRecord(h->fam_ev[at], st) != hipSuccess) return -1;
+  h->fam_marks.push_back({fam, at});
+  return (int)at;
+}
+void fam_end(SlamEngine* h, int slot, hipStream_t st) {
+  if (slot >= 0) (void)hipEventRecord(h->fam_ev[(size_t)slot + 1], st);
+}
+// CK around a launch (or a short run of launches) of one family on one stream
+#define TK(fam, stream_, expr)                      \
+  do {                                              \
+    const int _slot = fam_begin(h, (fam), (stream_)); \
+    CK(expr);                                       \
+    fam_end(h, _slot, (stream_));                   \
+  } while (0)
+
 int ensure_side(SlamEngine* h) {
   if (h->side) return 0;
   hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
@@ -268,14 +317,16 @@ int ensure_side(SlamEngine* h) {
   return 0;
 }
 int ensure_wside(SlamEngine* h) {
-  if (h->wside && h->wside_cus_applied == h->wside_cus) return 0;
-  hipError_t e;
-  if (h->wside) {  // the mask changed: replace the stream
+  if (h->wside && h->wside_cus_applied == h->wside_cus && (!h->wgrad_small_stream || h->wside2)) return 0;
+  hipError_t e = hipSuccess;
+  if (h->wside && h->wside_cus_applied != h->wside_cus) {  // the mask changed: replace the stream
     (void)hipStreamSynchronize(h->wside);
     (void)hipStreamDestroy(h->wside);
     h->wside = nullptr;
   }
-  if (h->wside_cus > 0) {
+  if (h->wside) {
+    // keep it
+  } else if (h->wside_cus > 0) {
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int n = h->wside_cus > 256 ? 256 : h->wside_cus;
     for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
@@ -285,8 +336,12 @@ int ensure_wside(SlamEngine* h) {
   }
   if (e != hipSuccess) return (int)e;
   h->wside_cus_applied = h->wside_cus;
+  if (h->wgrad_small_stream && !h->wside2) {
+    e = hipStreamCreateWithFlags(&h->wside2, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+  }
   if (h->ev_w.empty()) {
-    h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
+    h->ev_w.resize((size_t)(h->d.n_layers + 2) * 8);
     for (auto& ev : h->ev_w) {
       e = hipEventCreateWithFlags(&ev, sync_event_flags());
       if (e != hipSuccess) return (int)e;
@@ -312,7 +367,9 @@ int wait_params(SlamEngine* h, int64_t lo, int64_t hi, hipStream_t st) {
     SlamEngine::ParamWait& w = h->pwaits[i];
     if (w.lo < hi && lo < w.hi) {
       hipError_t r;
-      if (h->time_param_waits) {  // two timing events per wait are two more packets on the caller's stream: measurement runs only
+      // two timing events per wait are two more packets on the caller's stream: measurement runs only. The pool is read and
+      // reset by slam_param_wait_ms; a caller that never reads it stops being timed after 2048 waits instead of growing it
+      if (h->time_param_waits && h->pw_used + 2 <= 4096) {
         if (h->pw_used + 2 > h->pw_ev.size()) {
           for (int k = 0; k < 2; ++k) {
             hipEvent_t e;
@@ -380,7 +437,7 @@ int adamw_model(SlamEngine* h, int mode, float* master, void* m, void* v, const 
 
 extern "C" {
 
-const char* slam_version(void) { return "slam-engine gfx950 r3"; }
+const char* slam_version(void) { return "slam-engine gfx950 r4"; }
 
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
@@ -511,6 +568,10 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     h->time_gateup = value != 0;
     return SLAM_OK;
   }
+  if (!strcmp(key, "norm_bwd_lean")) { norm_bwd_tune(value != 0, 0); return SLAM_OK; }      // process-wide (kernel selection)
+  if (!strcmp(key, "norm_bwd_blocks")) { norm_bwd_tune(-1, (int)value); return SLAM_OK; }
+  if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
+  if (!strcmp(key, "bwd_wgrad_small_stream") && h) { h->wgrad_small_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -543,6 +604,7 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     h->cur_seg_s = h->seg_s;
     h->cur_seg_e = h->seg_e;
   }
+  if (h->time_families) h->fam_marks.clear();  // the marks of a step = its last forward + backward
   CK(attn_plan(h->cur_seg_s, h->cur_seg_e, M, d.head_dim, h->attn_tune, h->attn_plan_buf, st));
   // queries are stored pre-scaled by head_dim^-0.5 * log2(e) (folded into their rotation tables: one rounding), so the
   // attention kernels' scores leave the matrix pipe in the exp2 domain
@@ -556,36 +618,42 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
     LayerAct& a = h->la[l];
     CK(wait_chunk(h, 1 + l, st));
     CK(wait_params(h, o.ln1, o.ln1 + h->layer_stride, st));
-    CK(rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
+    TK(F_NORM_FWD, st, rmsnorm_fwd(h->hs[l], P + o.ln1, a.x1, a.rstd1, M, H, d.rms_eps, st));
     if (d.head_dim == 64 && (H % 64 == 0) && (h->QKV % 128 == 0)) {  // bias + RoPE fused into the projection epilogue
-      CK(gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, h->cosq, h->sinq, nH, nH + nKV, M, h->QKV, H, st));
+      TK(F_QKV_FWD, st, gemm_nt_rope(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, h->cosb, h->sinb, h->cosq, h->sinq, nH, nH + nKV, M, h->QKV, H, st));
     } else {
+      const int slot = fam_begin(h, F_QKV_FWD, st);
       CK(gemm_nt(a.x1, P + o.wqkv, a.qkv, P + o.bqkv, nullptr, M, h->QKV, H, st));
       CK(rope_apply(a.qkv, h->QKV, M, nH + nKV, d.head_dim, h->cosb, h->sinb, 0, st, nH, qscale));
+      fam_end(h, slot, st);
     }
-    CK(attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, h->attn_tune, M, nH, nKV, d.head_dim, st));
-    CK(gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
-    CK(rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
+    TK(F_ATTN_FWD, st, attn_fwd(a.qkv, a.o, a.lse, h->cur_seg_s, h->attn_plan_buf, h->attn_tune, M, nH, nKV, d.head_dim, st));
+    TK(F_O_FWD, st, gemm_nt(a.o, P + o.wo, a.hmid, nullptr, h->hs[l], M, H, nH * d.head_dim, st));
+    TK(F_NORM_FWD, st, rmsnorm_fwd(a.hmid, P + o.ln2, a.x2, a.rstd2, M, H, d.rms_eps, st));
     const bool timed = h->time_gateup && h->tg_ev.size() == (size_t)(2 * L);
     if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l], st));
-    if (h->fuse_swiglu) {
-      CK(gemm_nt_swiglu(a.x2, P + o.wgu, a.gu, a.act, M, 2 * I, H, st));
-    } else {
-      CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
-      CK(swiglu_fwd(a.gu, a.act, M, I, GU_BLK, st));
+    {
+      const int slot = fam_begin(h, F_GATEUP_FWD, st);
+      if (h->fuse_swiglu) {
+        CK(gemm_nt_swiglu(a.x2, P + o.wgu, a.gu, a.act, M, 2 * I, H, st));
+      } else {
+        CK(gemm_nt(a.x2, P + o.wgu, a.gu, nullptr, nullptr, M, 2 * I, H, st));
+        CK(swiglu_fwd(a.gu, a.act, M, I, GU_BLK, st));
+      }
+      fam_end(h, slot, st);
     }
     if (timed) CK((int)hipEventRecord(h->tg_ev[2 * l + 1], st));
-    CK(gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
+    TK(F_DOWN_FWD, st, gemm_nt(a.act, P + o.wd, h->hs[l + 1], nullptr, a.hmid, M, H, I, st));
   }
   CK(join_optimizer(h, st));
   CK(join_params(h, st));
-  CK(rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
+  TK(F_NORM_FWD, st, rmsnorm_fwd(h->hs[L], P + h->off_norm, h->hf, h->rstdf, M, H, d.rms_eps, st));
   const int VP = h->vpad;
-  CK(gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
+  TK(F_HEAD_FWD, st, gemm_nt(h->hf, P + h->off_embed, h->logits, nullptr, nullptr, M, VP, H, st));
   h->have_loss = false;
   if (logits_out) CK(copy_cols(h->logits, VP, (bf16_t*)logits_out, d.vocab, M, d.vocab, st));
   if (labels) {
-    CK(cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VP,
+    TK(F_LOSS, st, cross_entropy(h->logits, labels, num_items, h->dlogits, h->row_loss, h->scal + 0, h->scal + 1, B, T, VP,
                      d.vocab, h->logit_mask, st));
     CK((int)hipMemcpyAsync(loss_out, h->scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
     h->have_loss = true;
@@ -639,32 +707,39 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   //    needs its work as early as it can have it.
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
+  const bool three = two && h->wgrad_small_stream != 0 && h->wside2 != nullptr;
   GemmTuneScope tune_scope(&h->gemm_tune);
   struct SharedGuard {  // dgrad launches of this call may plan for a GPU they share with the wgrad stream
     GemmTune* t;
     SharedGuard(GemmTune* t_, int on) : t(t_) { t->shared = on; }
     ~SharedGuard() { t->shared = 0; }
   } shared_guard(&h->gemm_tune, two ? 1 : 0);
-  hipStream_t ws = two ? h->wside : st;
+  hipStream_t ws = two ? h->wside : st;       // the long weight-gradient launches (Wd, Wgu)
+  hipStream_t ws2 = three ? h->wside2 : ws;   // the short ones (Wo, Wqkv, head, embedding); owns the second slab workspace
   int ev_used = 0;
-  auto fork = [&]() -> int {  // side stream continues after everything enqueued on main so far
-    if (!two) return 0;
+  auto edge = [&](hipStream_t from, hipStream_t to) -> int {  // `to` continues after everything enqueued on `from` so far
+    if (from == to) return 0;
     if ((size_t)ev_used >= h->ev_w.size()) return SLAM_ESTATE;
     hipEvent_t e = h->ev_w[ev_used++];
-    hipError_t r = hipEventRecord(e, st);
+    hipError_t r = hipEventRecord(e, from);
     if (r != hipSuccess) return (int)r;
-    return (int)hipStreamWaitEvent(ws, e, 0);
+    return (int)hipStreamWaitEvent(to, e, 0);
   };
-  // dW (+)= a^T b on the weight-gradient stream
-  auto wgrad = [&](const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
-    if (int r = fork()) return r;
-    return gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
+  auto fork = [&]() -> int { return two ? edge(st, ws) : 0; };
+  // dW (+)= a^T b on a weight-gradient stream
+  auto wgrad = [&](int fam, bool small, const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
+    hipStream_t t = small ? ws2 : ws;
+    if (two) { if (int r = edge(st, t)) return r; }
+    const int slot = fam_begin(h, fam, t);
+    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, (small && three) ? h->gemm_ws2 : h->gemm_ws, h->gemm_ws_bytes, t, two ? 1 : 0);
+    fam_end(h, slot, t);
+    return r;
   };
 
-  CK(wgrad(h->dlogits, h->hf, G + h->off_embed, VP, H));
-  CK(dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
+  CK(wgrad(F_HEAD_WGRAD, true, h->dlogits, h->hf, G + h->off_embed, VP, H));
+  TK(F_HEAD_DGRAD, st, dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
-  CK(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
+  TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
   int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
@@ -675,42 +750,48 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     bf16_t* dh2 = h->hs[l + 1];                              // grad wrt hmid[l]: hs[l+1] was last read by the norm backward above it
     bf16_t* dqkv = l + 1 < L ? h->la[l + 1].qkv : h->dqkv;   // layer l+1's q|k|v were last read by its attention backward
     // MLP
-    CK(wgrad(dh, a.act, G + o.wd, H, I));
-    if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
-      CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
-    } else {
-      CK(dgrad(dh, o.wd, h->dact, H, I));
-      CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
+    CK(wgrad(F_WD_WGRAD, false, dh, a.act, G + o.wd, H, I));
+    {
+      const int slot = fam_begin(h, F_DOWN_DGRAD, st);
+      if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
+        CK(gemm_nt_dswiglu(dh, Pt + o.wd, a.gu, M, I, H, st));  // d(act) stays in registers; a.gu -> d(gate|up)
+      } else {
+        CK(dgrad(dh, o.wd, h->dact, H, I));
+        CK(swiglu_bwd(a.gu, h->dact, M, I, GU_BLK, st));  // a.gu now holds d(gate|up)
+      }
+      fam_end(h, slot, st);
     }
-    CK(wgrad(a.gu, a.x2, G + o.wgu, 2 * I, H));
-    CK(dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
-    CK(rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
+    CK(wgrad(F_WGU_WGRAD, false, a.gu, a.x2, G + o.wgu, 2 * I, H));
+    TK(F_GATEUP_DGRAD, st, dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
+    TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(wgrad(dh2, a.o, G + o.wo, H, HD));
-    CK(dgrad(dh2, o.wo, h->d_o, H, HD));
-    CK(attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
+    CK(wgrad(F_WO_WGRAD, true, dh2, a.o, G + o.wo, H, HD));
+    TK(F_O_DGRAD, st, dgrad(dh2, o.wo, h->d_o, H, HD));
+    TK(F_ATTN_BWD, st, attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(wgrad(dqkv, a.x1, G + o.wqkv, h->QKV, H));
-    CK(dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
+    CK(wgrad(F_WQKV_WGRAD, true, dqkv, a.x1, G + o.wqkv, h->QKV, H));
+    TK(F_QKV_DGRAD, st, dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
     dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
-    CK(rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
+    TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
     // bucket boundaries: every `bl` layers from the top, and after each of the last two layers so that the
     // final all-reduce (exposed behind the end of backward) only carries layer 0 + the embedding
     const bool boundary = cb && l > 0 && ((((L - l) % bl) == 0) || l <= 2);
     if (l == 0 || boundary) {
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
-      const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
+      const int nbl = rmsnorm_bwd_rows(M, H), nbc = colsum_blocks(M);
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st));
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st));
       CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st));
       fin_hi = l;
     }
     if (boundary) {
-      // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
-      // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
+      // the side streams are in order: the last launch of layer l on each covers every wgrad of the range. Order the long
+      // stream after the finish kernels above and after the short stream as well, and hand IT to the consumer
+      // (slam_bucket_stream): main does not stall here.
       CK(fork());
+      if (three) CK(edge(ws2, ws));
       h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
       h->bucket_stream = nullptr;
@@ -719,19 +800,21 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   }
   // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
   // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
-  // (on the wgrad stream: ordered after the head's contribution to the same rows)
-  CK(fork());
-  if (VP == VPAD_SMALL) {
-    CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
-    CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
-  } else {
-    CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
+  // (on the stream of the head's weight gradient: ordered after its contribution to the same rows)
+  if (two) CK(edge(st, ws2));
+  {
+    const int slot = fam_begin(h, F_EMBED_WGRAD, ws2);
+    if (VP == VPAD_SMALL) {
+      CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws2));
+      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, three ? h->gemm_ws2 : h->gemm_ws, h->gemm_ws_bytes, ws2, two ? 1 : 0));
+    } else {
+      CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws2));
+    }
+    fam_end(h, slot, ws2);
   }
   if (two) {  // join: everything after slam_backward on `stream` sees complete gradients
-    if ((size_t)ev_used >= h->ev_w.size()) return h->fail(SLAM_ESTATE, "event pool exhausted");
-    hipEvent_t e = h->ev_w[ev_used++];
-    CK((int)hipEventRecord(e, ws));
-    CK((int)hipStreamWaitEvent(st, e, 0));
+    CK(edge(ws, st));
+    if (three) CK(edge(ws2, st));
   }
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
@@ -920,6 +1003,40 @@ int slam_gateup_launch_ms(SlamEngine* h, float* ms_out, int32_t n) {
     if (e != hipSuccess) return h->fail((int)e, "gate|up timing events are not recorded");
     ms_out[l] = ms;
   }
+  return SLAM_OK;
+}
+
+const char* slam_family_name(int32_t family) { return (family >= 0 && family < F_COUNT) ? kFamName[family] : nullptr; }
+
+int slam_family_ms(SlamEngine* h, int32_t* family_out, float* ms_out, int32_t capacity, int32_t* count_out) {
+  if (!h || !family_out || !ms_out || !count_out || capacity < 0) return SLAM_EINVAL;
+  int32_t n = 0;
+  for (const auto& mk : h->fam_marks) {
+    if (n >= capacity) break;
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(h->fam_ev[mk.second + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->fam_ev[mk.second], h->fam_ev[mk.second + 1]);
+    if (e != hipSuccess) return h->fail((int)e, "family timing events are not recorded (set time_families before the step)");
+    family_out[n] = mk.first;
+    ms_out[n] = ms;
+    ++n;
+  }
+  *count_out = n;
+  return SLAM_OK;
+}
+
+// fp32 gradient range <-> bf16 communication image (the data-parallel exchange in bf16: the reference's DDP reduces bf16
+// gradients because its parameters are bf16, config/model/slam.yaml:9)
+int slam_pack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, void* dst_bf16, slam_stream_t stream) {
+  if (!h || !dst_bf16 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3)) return SLAM_EINVAL;
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  if (count) CK(f32_to_bf16(h->grads + offset, (bf16_t*)dst_bf16, (size_t)count, (hipStream_t)stream));
+  return SLAM_OK;
+}
+int slam_unpack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, const void* src_bf16, slam_stream_t stream) {
+  if (!h || !src_bf16 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3)) return SLAM_EINVAL;
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  if (count) CK(bf16_to_f32((const bf16_t*)src_bf16, h->grads + offset, (size_t)count, (hipStream_t)stream));
   return SLAM_OK;
 }
 

@@ -253,12 +253,19 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
     # load-or-build is decided ONCE (rank 0, on the completion marker written after the last shard) and broadcast: ranks
     # that looked at the directory themselves could see a half-written cache, take different branches and miss the barrier
     have_cache = bool(saved) and os.path.isfile(os.path.join(saved, "_COMPLETE"))
+    # a directory with shards but no marker was written before the marker existed, or by an interrupted run: the reference
+    # treats an existing directory as the cache (hf_dataset.py:31-33) - re-tokenising over it would mix old and new shards
+    legacy = bool(saved) and not have_cache and os.path.isdir(os.path.join(saved, "train")) and bool(os.listdir(os.path.join(saved, "train")))
     import torch.distributed as _dist
     _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
     if _multi:
-        flag = [have_cache]
+        flag = [have_cache, legacy]
         _dist.broadcast_object_list(flag, src=0)
-        have_cache = bool(flag[0])
+        have_cache, legacy = bool(flag[0]), bool(flag[1])
+    if legacy:
+        raise RuntimeError(f"{saved} holds token shards but no _COMPLETE marker: either an earlier version wrote it (verify it, then "
+                           f"`touch {os.path.join(saved, '_COMPLETE')}` to accept it as the cache) or a run was interrupted while "
+                           f"writing it (delete the directory to rebuild)")
     if saved and have_cache:
         logger.info(f"Loading dataset from {saved}")
         dataset = {s: TokenShardDataset(os.path.join(saved, s)) for s in ("train", "validation")

@@ -86,6 +86,10 @@ def load_library(path: Optional[str] = None):
         "slam_add_param_wait": (C.c_int, [vp, i64, i64, vp]),
         "slam_param_wait_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "slam_gateup_launch_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int32]),
+        "slam_family_ms": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
+        "slam_family_name": (C.c_char_p, [C.c_int32]),
+        "slam_pack_grads_bf16": (C.c_int, [vp, i64, i64, vp, vp]),
+        "slam_unpack_grads_bf16": (C.c_int, [vp, i64, i64, vp, vp]),
         "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
@@ -319,6 +323,23 @@ class Engine:
         out = (C.c_float * n_layers)()
         self._ck(self.lib.slam_gateup_launch_ms(self.h, out, n_layers))
         return [float(v) for v in out]
+
+    def family_ms(self, capacity: int = 4096):
+        """[(family name, ms)] of the last forward + backward in launch order (option time_families = 1)."""
+        fam = (C.c_int32 * capacity)()
+        ms = (C.c_float * capacity)()
+        n = C.c_int32(0)
+        self._ck(self.lib.slam_family_ms(self.h, fam, ms, capacity, C.byref(n)))
+        return [(self.lib.slam_family_name(int(fam[i])).decode(), float(ms[i])) for i in range(n.value)]
+
+    def pack_grads_bf16(self, offset: int, count: int, dst_bf16, stream=None):
+        """dst_bf16[0:count] = bf16(grads[offset:offset+count]); dst_bf16: a bf16 device tensor (view) of >= count elements."""
+        self._ck(self.lib.slam_pack_grads_bf16(self.h, int(offset), int(count), _ptr(dst_bf16),
+                                               stream if stream is not None else current_stream_ptr()))
+
+    def unpack_grads_bf16(self, offset: int, count: int, src_bf16, stream=None):
+        self._ck(self.lib.slam_unpack_grads_bf16(self.h, int(offset), int(count), _ptr(src_bf16),
+                                                 stream if stream is not None else current_stream_ptr()))
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))

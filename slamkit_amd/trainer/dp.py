@@ -50,11 +50,15 @@ def host_group():
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None):
+    def __init__(self, flat_grads: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None, engine=None):
         """comm_dtype = torch.bfloat16 exchanges the buckets in bf16 through a staging buffer, like the reference's
         DDP does when the parameters (hence the gradients) are bf16: half the bytes on the xGMI links for two
-        conversion passes per bucket; None (default) reduces the fp32 buffer in place."""
+        conversion passes per bucket; None (default) reduces the fp32 buffer in place.
+        engine: the slamkit_amd Engine that owns `flat_grads` - the bf16 staging passes run as ITS kernels on the
+        communication stream (slam_pack_grads_bf16 / slam_unpack_grads_bf16), so nothing between backward and the wire is a
+        torch kernel; without one (the CPU stub models of the gloo tests) the conversion is a tensor copy."""
         self.flat = flat_grads
+        self.engine = engine if (engine is not None and hasattr(engine, "pack_grads_bf16")) else None
         self.group = group
         self.comm_dtype = comm_dtype if comm_dtype not in (None, flat_grads.dtype) else None
         self.stage = None
@@ -66,6 +70,20 @@ class GradBucketReducer:
         self.force = os.environ.get("SLAM_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
         self.time_buckets = False   # bracket every bucket's collective with timing events on the communication stream
         self._bucket_ev, self._last_bucket_ev = [], []
+
+    def _pack(self, offset: int, count: int, st: torch.Tensor):
+        """st[0:count] = comm_dtype(grads[offset:offset+count]) on the current stream."""
+        if self.engine is not None and self.flat.is_cuda and st.dtype == torch.bfloat16 and not ((offset | count) & 3):
+            self.engine.pack_grads_bf16(offset, count, st)
+        else:
+            st.copy_(self.flat[offset:offset + count])
+
+    def _unpack(self, offset: int, count: int, st: torch.Tensor):
+        """grads[offset:offset+count] = fp32(st[0:count]) on the current stream."""
+        if self.engine is not None and self.flat.is_cuda and st.dtype == torch.bfloat16 and not ((offset | count) & 3):
+            self.engine.unpack_grads_bf16(offset, count, st)
+        else:
+            self.flat[offset:offset + count].copy_(st)
 
     def _timed(self, tag, fn):
         """Run fn() (collectives on the current = communication stream); with time_buckets, between two timing events."""
@@ -115,18 +133,18 @@ class GradBucketReducer:
                     self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 else:  # cast -> reduce -> cast back, all ordered on the side stream
                     st = self.stage[offset:offset + count]
-                    st.copy_(view)
+                    self._pack(offset, count, st)
                     dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
-                    view.copy_(st)
+                    self._unpack(offset, count, st)
             with torch.cuda.stream(self.side):
                 self._timed(("all_reduce", offset, count), exchange)
         elif self.comm_dtype is None:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             st = self.stage[offset:offset + count]
-            st.copy_(view)
+            self._pack(offset, count, st)
             dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
-            view.copy_(st)
+            self._unpack(offset, count, st)
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket. The stall of the compute stream (= the part of
@@ -165,8 +183,8 @@ class ShardedGradReducer(GradBucketReducer):
     include/slam_engine.h, slam_grad_sumsq_chunks). The few thousand elements above the last multiple (the top of the
     flat buffer) stay replicated: all-reduced and updated by every rank."""
 
-    def __init__(self, flat_grads, flat_params, chunk_elems: int, group=None, comm_dtype=None):
-        super().__init__(flat_grads, group=group, comm_dtype=comm_dtype)
+    def __init__(self, flat_grads, flat_params, chunk_elems: int, group=None, comm_dtype=None, engine=None):
+        super().__init__(flat_grads, group=group, comm_dtype=comm_dtype, engine=engine)
         self.params = flat_params
         self.n = flat_grads.numel()
         w = max(1, self.world)
@@ -176,6 +194,7 @@ class ShardedGradReducer(GradBucketReducer):
         self.buckets = []   # (lo, hi) of this step's communicated buckets
         self.owned = []     # (offset, count) this rank owns after finish()
         self.active = False
+        self._tail_done = False   # the replicated tail [top, n) of this step has been handed to the communication stream
         self._ag_events = []
 
     @property
@@ -203,16 +222,19 @@ class ShardedGradReducer(GradBucketReducer):
             if self.stage is None:
                 self.stage = torch.empty(self.n, dtype=self.comm_dtype, device=self.flat.device)
             st = self.stage[lo:hi]
-            st.copy_(view)
+            self._pack(lo, hi - lo, st)
             dist.reduce_scatter_tensor(st[r * s:(r + 1) * s], st, op=dist.ReduceOp.SUM, group=self.group)
-            view[r * s:(r + 1) * s].copy_(st[r * s:(r + 1) * s])
+            self._unpack(lo + r * s, s, st[r * s:(r + 1) * s])
 
     def on_bucket(self, offset: int, count: int, ready_stream: Optional[int] = None):
         self.ranges.append((offset, count))
         if (self.world == 1 and not self.force) or count <= 0:
             return
         self.active = True
-        if offset + count >= self.n and self.top < self.n:  # first range of a backward: the replicated tail
+        if not self._tail_done and self.top < self.n and offset <= self.top:
+            # the replicated tail [top, n) is final once a reported range reaches down to `top` - normally the first one; a
+            # model smaller than world x chunk (top == 0) or a first range shorter than the tail gets it with a later callback
+            self._tail_done = True
             t0 = self.top
             self._on_side(ready_stream, lambda: dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group),
                           tag=("all_reduce (replicated tail)", t0, self.n - t0))
@@ -240,7 +262,8 @@ class ShardedGradReducer(GradBucketReducer):
         self.owned = [(lo + r * ((hi - lo) // w), (hi - lo) // w) for lo, hi in self.buckets]
         self.last_buckets = list(self.buckets)
         self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
-        self.buckets, self.cut_hi, self.active = [], self.top, False
+        assert self._tail_done or self.top >= self.n, "the replicated tail was never exchanged"
+        self.buckets, self.cut_hi, self.active, self._tail_done = [], self.top, False, False
         covered = sorted(self.ranges)
         self.ranges = []
         return covered

@@ -102,9 +102,9 @@ class SLAMDPOTrainer(SLAMTrainer):
             g = a.beta * torch.sigmoid(-x) / (n * nm * self.world)
             coef = torch.cat([g, -g])
             last = i == nm - 1
-            self.model.backward_sequence_loss(coef, B2, T, 1.0,
-                                              bucket_layers=a.ddp_bucket_layers if (last and self.world > 1) else 0,
-                                              bucket_cb=self.reducer.on_bucket if (last and self.world > 1) else None)
+            dp = last and (self.world > 1 or self.reducer.force)
+            self.model.backward_sequence_loss(coef, B2, T, 1.0, bucket_layers=a.ddp_bucket_layers if dp else 0,
+                                              bucket_cb=self.reducer.on_bucket if dp else None)
             self._loss_acc += losses.mean().detach() / nm
         self._loss_n += 1
         seen = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
@@ -114,7 +114,7 @@ class SLAMDPOTrainer(SLAMTrainer):
             seen = float(t)
         self.state.num_input_tokens_seen += int(seen)
         self.reducer.finish()
-        self._clip_and_update(lr, zero_grad=True)
+        self._update(lr, zero_grad=True)  # replicated or sharded (ddp_algo = rs_ag), as the reducer left the gradients
         self.state.global_step += 1
 
     @torch.no_grad()

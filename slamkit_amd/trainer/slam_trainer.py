@@ -70,7 +70,8 @@ class SLAMTrainer:
             if getattr(self.args, "overlap_optimizer", False):
                 raise ValueError("ddp_algo=rs_ag runs the optimizer on shards; overlap_optimizer belongs to the replicated step")
             chunk, n_chunks = model.engine.grad_chunk_info()
-            self.reducer = ShardedGradReducer(model.flat_grads, model.flat_params, chunk, comm_dtype=getattr(torch, cd) if cd else None)
+            self.reducer = ShardedGradReducer(model.flat_grads, model.flat_params, chunk, comm_dtype=getattr(torch, cd) if cd else None,
+                                              engine=model.engine)
             if args.logging_steps and hasattr(model.engine, "set_option"):
                 try:  # the logged `exposed_param_gather_ms` needs the waits bracketed by timing events (two more packets per wait)
                     model.engine.set_option("time_param_waits", 1)
@@ -78,7 +79,7 @@ class SLAMTrainer:
                     pass
             self._chunk_sums = torch.zeros(n_chunks, dtype=torch.float32, device=dev)
         else:
-            self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None)
+            self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None, engine=model.engine)
         if (self.world > 1 or self.reducer.force) and torch.device(dev).type == "cuda":
             from .. import check_hw_queues
             check_hw_queues(8)
@@ -187,31 +188,63 @@ class SLAMTrainer:
                 except queue.Empty:
                     th.join(timeout=0.05)
 
+    def _counts_ahead(self, groups):
+        """(micro-batches of step k, handle of their count all-reduce), with the all-reduce of step k + 1 POSTED before step
+        k is yielded - the blocking per-step collective of the step loop becomes a wait on work that finished a step ago.
+        Subclasses with their own optimizer_step (DPO) keep their own counting: handle None."""
+        if type(self).optimizer_step is not SLAMTrainer.optimizer_step or not (self.world > 1 or self.reducer.force):
+            for micro in groups:
+                yield micro, None
+            return
+        prev = None
+        for micro in groups:
+            c = self.local_counts(micro)
+            cur = (micro, (c, self.post_counts(*c)))
+            if prev is not None:
+                yield prev
+            prev = cur
+        if prev is not None:
+            yield prev
+
     # ---- one optimizer step over `micro` collated CPU micro-batches -------------------------------------
-    def optimizer_step(self, micro: List[Dict[str, torch.Tensor]], lr: float, counts=None):
+    def local_counts(self, micro):
+        """(num_items_in_batch, tokens seen) of this rank for one optimizer step, counted on the host from the CPU labels."""
+        a = self.args
+        local_items = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
+        if a.min_token_id_count is None and a.max_token_id_count is None:
+            return local_items, local_items
+        return local_items, float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
+
+    def post_counts(self, local_items: float, local_seen: float):
+        """Start the all-reduce of one optimizer step's token counts and return a handle for `optimizer_step(counts_handle=)`.
+        The reference gathers the counts with a device collective + `.item()` on EVERY micro-step (slam_trainer.py:70); here
+        it is ONE host-side (gloo) all-reduce per optimizer step, and train() posts it one step AHEAD (the collate thread's
+        batches are already there), so the step loop never waits for it. All ranks must post in the same order."""
+        if not (self.world > 1 or self.reducer.force):
+            return None, torch.tensor([local_items, local_seen], dtype=torch.float64)
+        if self.host_group is not None:
+            t = torch.tensor([local_items, local_seen], dtype=torch.float64)
+            return dist.all_reduce(t, group=self.host_group, async_op=True), t
+        # no gloo: device collective on the RCCL group (costs one host sync per step when the result is read)
+        t = torch.tensor([local_items, local_seen], dtype=torch.float64, device=self.model.device)
+        dist.all_reduce(t)
+        return None, t
+
+    def optimizer_step(self, micro: List[Dict[str, torch.Tensor]], lr: float, counts=None, counts_handle=None):
         """`counts` = (local num_items, local tokens seen) when the caller already knows them (device-
-        resident synthetic batches); otherwise counted on the host from the CPU labels."""
+        resident synthetic batches); otherwise counted on the host from the CPU labels. `counts_handle` = what
+        post_counts returned for THIS step's local counts (posted earlier); without it the all-reduce is posted here."""
         a = self.args
         if counts is not None:
             local_items, local_seen = float(counts[0]), float(counts[1])
         else:
-            local_items = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
-            if a.min_token_id_count is None and a.max_token_id_count is None:
-                local_seen = local_items
-            else:
-                local_seen = float(sum(self.get_num_tokens(mb["labels"]) for mb in micro))
-        if self.world > 1 or self.reducer.force:
-            # host-side (gloo) all-reduce: the counts come from CPU labels, and a device collective here
-            # would stall the host behind the previous step's kernels
-            if self.host_group is not None:
-                t = torch.tensor([local_items, local_seen], dtype=torch.float64)
-                dist.all_reduce(t, group=self.host_group)
-            else:  # no gloo: device collective on the RCCL group (costs one host sync per step)
-                t = torch.tensor([local_items, local_seen], dtype=torch.float64, device=self.model.device)
-                dist.all_reduce(t)
-            glob_items, glob_seen = (float(x) for x in t.tolist())
-        else:
-            glob_items, glob_seen = local_items, local_seen
+            local_items, local_seen = self.local_counts(micro)
+        if counts_handle is None:
+            counts_handle = self.post_counts(local_items, local_seen)
+        work, t = counts_handle
+        if work is not None:
+            work.wait()
+        glob_items, glob_seen = (float(x) for x in t.tolist())
         if a.average_tokens_across_devices:
             n_items, scale = glob_items, 1.0           # sum over ranks of d(local_sum / global_count)
         else:
@@ -227,11 +260,17 @@ class SLAMTrainer:
         self._loss_n += 1
         self.reducer.finish()
         self.state.num_input_tokens_seen += int(glob_seen)
-        if getattr(self.reducer, "owned", None) is not None and (self.world > 1 or self.reducer.force):
-            self._clip_and_update_sharded(lr, zero_grad=not a.overwrite_first_grad)
-        else:
-            self._clip_and_update(lr, zero_grad=not a.overwrite_first_grad)
+        self._update(lr, zero_grad=not a.overwrite_first_grad)
         self.state.global_step += 1
+
+    def _update(self, lr: float, zero_grad: bool):
+        """Clip + AdamW in the form the gradient exchange left the buffer in: a sharded reducer (ddp_algo = rs_ag) holds the
+        summed gradients of this rank's shards only, so the update must be the sharded one followed by the parameter
+        all-gather; every subclass step (DPO) goes through here too."""
+        if getattr(self.reducer, "owned", None) is not None and (self.world > 1 or self.reducer.force):
+            self._clip_and_update_sharded(lr, zero_grad=zero_grad)
+        else:
+            self._clip_and_update(lr, zero_grad=zero_grad)
 
     def _clip_and_update(self, lr: float, zero_grad: bool):
         """clip_grad_norm_ + AdamW on the flat buffers, in the configured state precision."""
@@ -341,9 +380,12 @@ class SLAMTrainer:
                 break
             batches = self._epoch_batches(epoch)[skip:]
             skip = 0
-            for micro in self._micro_batches(batches, a.gradient_accumulation_steps):
+            for micro, handle in self._counts_ahead(self._micro_batches(batches, a.gradient_accumulation_steps)):
                 lr = a.learning_rate * lr_lambda(a, self.state.global_step, max_steps)
-                self.optimizer_step(micro, lr)
+                if handle is None:
+                    self.optimizer_step(micro, lr)
+                else:
+                    self.optimizer_step(micro, lr, counts=handle[0], counts_handle=handle[1])
                 self.state.epoch = self.state.global_step / updates_per_epoch
                 for cb in self.callbacks:
                     cb.on_step_end(a, self.state, self.control)
@@ -363,6 +405,9 @@ class SLAMTrainer:
                     break
         if self._loss_n:
             self._log(a.learning_rate * lr_lambda(a, max(self.state.global_step - 1, 0), max_steps), t0, tokens0)
+        # rs_ag: master weights / moments of the shards other ranks own are stale until gathered - bring them up to date so
+        # that whatever reads the model or the optimizer state after train() (state_dict(float32), a final save) sees one copy
+        self._gather_optimizer_state()
         for cb in self.callbacks:
             cb.on_train_end(a, self.state, self.control)
         if torch.device(self.model.device).type == "cuda":

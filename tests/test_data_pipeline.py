@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from slamkit_amd.data import (DataCollatorForLanguageModeling, DataCollatorWithFlattening, TokenShardDataset,
@@ -100,6 +101,12 @@ def test_binary_shard_roundtrip_and_saved_ds_path(golden_data, tmp_path):
     assert ds2["train"].num_tokens == 620
     raw = np.fromfile(saved / "train" / "tokens.bin", dtype="<u2")
     assert raw[:6].tolist() == [1, 5, 51, 9, 256, 32]  # <S> + unit+2
+    # shards without the completion marker (an older cache, or an interrupted writer) are neither trusted nor overwritten
+    os.remove(saved / "_COMPLETE")
+    before = (saved / "train" / "tokens.bin").read_bytes()
+    with pytest.raises(RuntimeError, match="_COMPLETE"):
+        init_dataset(cfg, _tok())
+    assert (saved / "train" / "tokens.bin").read_bytes() == before
 
 
 def test_interleave_datasets_matches_hf_datasets_index_stream():

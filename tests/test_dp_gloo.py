@@ -51,6 +51,32 @@ def _worker(rank, world, port, q):
         assert red_b.finish() == [(0, 128), (128, 128)]
         assert torch.equal(flat_b, base_b * 3)
 
+        # 2c) sharded reducer (rs_ag): the replicated tail [top, n) is exchanged by the first callback that REACHES `top`,
+        #     not blindly by the first one (a first range shorter than the tail: its gradients are not final yet), and a
+        #     buffer smaller than world x chunk (top == 0) is all tail, exchanged with the last callback
+        from slamkit_amd.trainer.dp import ShardedGradReducer
+        n3, chunk = 200, 16                       # align = 32, top = 192, tail = [192, 200)
+        g3 = torch.zeros(n3)
+        red3 = ShardedGradReducer(g3, torch.zeros(n3), chunk)
+        assert red3.tail == (192, 8)
+        g3[196:] = rank + 1.0                      # "backward" wrote only the top of the buffer so far
+        red3.on_bucket(196, 4)                     # shorter than the tail: nothing may be exchanged yet
+        assert not red3._tail_done and not red3.buckets
+        g3[:196] = rank + 1.0                      # ... the rest arrives
+        red3.on_bucket(64, 132)
+        assert red3._tail_done and red3.buckets == [(64, 192)]
+        red3.on_bucket(0, 64)
+        red3.finish()
+        assert torch.equal(g3[192:], torch.full((8,), 3.0))          # whole tail reduced once, after it was final
+        assert all(float(g3[o]) == 3.0 and float(g3[o + c - 1]) == 3.0 for o, c in red3.owned)
+        small = torch.full((20,), rank + 1.0)      # n < align: top == 0
+        red4 = ShardedGradReducer(small, torch.zeros(20), chunk)
+        red4.on_bucket(10, 10)
+        assert not red4._tail_done
+        red4.on_bucket(0, 10)
+        red4.finish()
+        assert torch.equal(small, torch.full((20,), 3.0)) and red4.owned == []
+
         # 3) DP gradient equivalence with the oracle as the compute
         cfg = O.OracleConfig(n_layers=1, hidden=64, n_heads=1, n_kv_heads=1, head_dim=64, intermediate=128)
         sd = O.init_weights(cfg, seed=1, bias_std=0.02)

@@ -202,8 +202,10 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
     cfg, sd, sd_bf, m = tiny
     ids, lab = (torch.from_numpy(golden_npz[k]) for k in ("pad_ids", "pad_labels"))
 
-    def run(two):
+    def run(two, three=0, timed=0):
         m.engine.set_option("bwd_wgrad_stream", two)
+        m.engine.set_option("bwd_wgrad_small_stream", three)  # the short weight gradients on a third stream (own slab workspace)
+        m.engine.set_option("time_families", timed)           # timing-event pairs around every launch must not change a bit
         m.zero_grad()
         got = []
         for rep in range(3):  # back-to-back backwards: the side stream of one must not run into the next
@@ -216,9 +218,14 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
         m.engine.set_option("gemm_tn_bal_bg_max_split", 8)  # same split plans on both paths
         m.engine.set_option("gemm_tn224_bg_min_m", 1 << 30)
         m.engine.set_option("gemm_nt224", 0)
-        outs = [run(0), run(1), run(1)]
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
-        assert outs[0][1] == outs[1][1]
+        outs = [run(0), run(1), run(1), run(1, 1), run(1, 1, 1)]
+        assert all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
+        assert all(outs[0][1] == o[1] for o in outs[1:])
+        fam = m.engine.family_ms()  # the last forward + backward, in launch order
+        names = [n for n, _ in fam]
+        L = cfg.n_layers
+        assert names.count("wgu_wgrad") == L and names.count("gateup_fwd") == L and names.count("attn_bwd") == L
+        assert names.count("norm_bwd") == 2 * L + 1 and all(ms >= 0.0 for _, ms in fam)
         m.engine.set_option("gemm_tn_bal_bg_max_split", 4)
         m.engine.set_option("gemm_tn224_bg_min_m", 4096)
         m.engine.set_option("gemm_nt224", 1)
@@ -226,9 +233,33 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
         assert rel_err(dflt[0], outs[0][0]) <= 1e-5
     finally:
         m.engine.set_option("bwd_wgrad_stream", 1)
+        m.engine.set_option("bwd_wgrad_small_stream", 0)
+        m.engine.set_option("time_families", 0)
         m.engine.set_option("gemm_tn_bal_bg_max_split", 4)
         m.engine.set_option("gemm_tn224_bg_min_m", 4096)
         m.engine.set_option("gemm_nt224", 1)
+
+
+def test_pack_unpack_grads_bf16_are_exact(tiny):
+    """slam_pack_grads_bf16 / slam_unpack_grads_bf16 (the bf16 gradient exchange's staging passes, engine kernels on the
+    communication stream): round-to-nearest-even packing bit-identical to a tensor conversion, widening exact, ranges
+    outside [offset, offset + count) untouched."""
+    cfg, sd, sd_bf, m = tiny
+    n = m.engine.n_params
+    g = torch.Generator(device="cuda").manual_seed(1)
+    m.flat_grads.copy_(torch.randn(n, device="cuda", generator=g) * torch.logspace(-6, 3, n, device="cuda"))
+    ref = m.flat_grads.clone()
+    stage = torch.full((n,), 7.0, dtype=torch.bfloat16, device="cuda")
+    off, cnt = 4096, ((n - 4096) // 8) * 4 + 4
+    m.engine.pack_grads_bf16(off, cnt, stage[off:off + cnt])
+    torch.cuda.synchronize()
+    assert torch.equal(stage[off:off + cnt], ref[off:off + cnt].to(torch.bfloat16))
+    assert bool((stage[:off] == 7).all()) and bool((stage[off + cnt:] == 7).all())
+    m.engine.unpack_grads_bf16(off, cnt, stage[off:off + cnt])
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_grads[off:off + cnt], ref[off:off + cnt].to(torch.bfloat16).float())
+    assert torch.equal(m.flat_grads[:off], ref[:off]) and torch.equal(m.flat_grads[off + cnt:], ref[off + cnt:])
+    m.zero_grad()
 
 
 def test_clip_and_adamw_step_vs_oracle(tiny, golden_npz):

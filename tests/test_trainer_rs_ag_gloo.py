@@ -130,3 +130,85 @@ def test_rs_ag_equals_all_reduce_world2_gloo(tmp_path):
     ref_p, ref_losses, _ = base._single_process_reference(True)
     p = torch.tensor(res[0][("float32", "rs_ag")][0])
     assert torch.allclose(p, ref_p, rtol=1e-5, atol=1e-6), float((p - ref_p).abs().max())
+
+
+# ---- DPO under rs_ag (SLAMDPOTrainer used the replicated clip + AdamW behind a sharded reducer) -------------
+class DpoStubLM(ShardStubLM):
+    """The UnitLM surface SLAMDPOTrainer drives: sequence_logps + backward_sequence_loss on the bag-of-embeddings LM."""
+
+    class _Cfg:
+        pad_token_id = 0
+    config = _Cfg()
+
+    def sequence_logps(self, input_ids, labels):
+        p = self.flat_params.detach().clone().requires_grad_(True)
+        E, W = p[: base.V * base.H].view(base.V, base.H), p[base.V * base.H:].view(base.V, base.H)
+        logp = torch.log_softmax(E[input_ids] @ W.t(), dim=-1)[:, :-1]
+        tgt = labels[:, 1:]
+        m = tgt != -100
+        ll = (logp.gather(-1, tgt.clamp(min=0)[..., None])[..., 0] * m).sum(1)
+        self._graph = (ll, p)
+        return ll.detach(), m.sum(1).float()
+
+    def backward_sequence_loss(self, seq_coef, B, T, grad_scale=1.0, bucket_layers=0, bucket_cb=None):
+        ll, p = self._graph
+        (g,) = torch.autograd.grad((seq_coef * (-ll)).sum() * grad_scale, p)
+        self.flat_grads.add_(g)
+        if bucket_cb is not None:
+            bucket_cb(base.V * base.H, base.V * base.H)
+            bucket_cb(0, base.V * base.H)
+
+
+def run_dpo(rank, world, algo, out_dir):
+    from slamkit_amd.trainer import DPOConfig, SLAMDPOTrainer
+
+    class Tok:
+        bos_token_id = eos_token_id = 1
+        def __call__(self, s, add_special_tokens=False):
+            return {"input_ids": list(s)}
+    g = torch.Generator().manual_seed(11)
+    ids = lambda lo, hi: torch.randint(2, base.V, (int(torch.randint(lo, hi, (1,), generator=g)),), generator=g).tolist()  # noqa: E731
+    rows = [{"prompt": ids(2, 5), "chosen": ids(3, 8), "rejected": ids(3, 8)} for _ in range(16)]
+    args = DPOConfig(output_dir=out_dir, per_device_train_batch_size=2, gradient_accumulation_steps=2, learning_rate=5e-3,
+                     warmup_steps=1, warmup_ratio=0.0, max_steps=2, logging_steps=1, ddp_bucket_layers=1, seed=5, save_steps=0,
+                     ddp_comm_dtype="float32", ddp_algo=algo, beta=0.1)
+    model, ref = DpoStubLM(seed=0), DpoStubLM(seed=0)
+    tr = SLAMDPOTrainer(model=model, ref_model=ref, args=args, train_dataset=rows, processing_class=Tok())
+    tr.train()
+    return model, tr
+
+
+def _dpo_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for algo in ("all_reduce", "rs_ag"):
+            model, tr = run_dpo(rank, world, algo, os.path.join(tmp, f"d{rank}"))
+            # train() gathered the sharded optimizer state: master / moments are whole on every rank
+            res[algo] = (model.flat_params.tolist(), model.flat_master.tolist(), tr.exp_avg.tolist(), type(tr.reducer).__name__)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dpo_rs_ag_equals_all_reduce_world2_gloo(tmp_path):
+    """SLAMDPOTrainer behind a ShardedGradReducer must run the sharded clip + AdamW and the parameter all-gather: both ranks
+    end with the parameters (and, after train(), the gathered optimizer state) of the all_reduce run, bit for bit."""
+    world, port = 2, base._free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dpo_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["rs_ag"][3] == "ShardedGradReducer" and res[0]["all_reduce"][3] == "GradBucketReducer"
+    init = DpoStubLM(seed=0).flat_params
+    assert not torch.equal(torch.tensor(res[0]["all_reduce"][0]), init)  # the steps moved the parameters
+    for i, name in enumerate(("params", "master", "exp_avg")):
+        a, b, c = torch.tensor(res[0]["rs_ag"][i]), torch.tensor(res[1]["rs_ag"][i]), torch.tensor(res[0]["all_reduce"][i])
+        assert torch.equal(a, b), (name, "ranks differ")
+        assert torch.equal(a, c), (name, float((a - c).abs().max()))

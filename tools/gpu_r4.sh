@@ -1,0 +1,36 @@
+#!/bin/bash
+# One gpurun call of round 4 (replaces the per-session scripts of round 3). Usage on the GPU box, from the repo root:
+#   bash tools/gpu_r4.sh <tag> <stage> [<stage> ...]
+# stages:  t:<pytest -k expression>   targeted GPU tests        full          the whole -m gpu suite
+#          b:<name>[:ENV=V,ENV=V]     bench.py A/B line         smoke         __graft_entry__.smoke()
+#          q:<name>[:ENV=V,...]       bench.py --workload qwen1p5b
+#          p:<script.py>[:args]       a tools/ probe            prof / pmc    kernel trace / counters of bench.py
+# Every stage runs under its own timeout; results under gpurun_out/<tag>_*.
+tag=$1; shift
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/${tag}
+for st in "$@"; do
+  kind=${st%%:*}; rest=${st#*:}; [ "$rest" = "$st" ] && rest=""
+  case $kind in
+    t) (timeout ${T_TIMEOUT:-900} python -m pytest tests -m gpu -x -q -k "$rest" 2>&1 | tail -${T_TAIL:-25}) > ${O}_t_$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40).log; tail -4 ${O}_t_*.log | tail -6;;
+    full) (timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 2>&1 | tail -60) > ${O}_pytest.log; tail -5 ${O}_pytest.log;;
+    smoke) (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3) > ${O}_smoke.log; tail -1 ${O}_smoke.log;;
+    b|q) name=${rest%%:*}; envs=${rest#*:}; [ "$envs" = "$rest" ] && envs=""
+       wl=""; [ "$kind" = q ] && wl="--workload qwen1p5b"
+       (env $(echo $envs | tr ',' ' ') timeout 500 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline ${BENCH_ARGS:---no-extras} $wl 2>${O}_bench_${name}.err | tail -1) > ${O}_bench_${name}.json
+       python - <<P
+import json
+try:
+    d = json.load(open("${O}_bench_${name}.json"))
+    r = d.get("roofline", {})
+    print("${name}", d["value"], d["ms_per_step"], d["config"].get("final_loss"), r.get("frac"), (r.get("in_step") or {}).get("dominant_by_time"))
+except Exception as e:
+    print("${name} FAILED", e)
+P
+       ;;
+    p) scr=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
+       (timeout 600 python tools/probes/$scr $(echo $args | tr ',' ' ') 2>&1 | tail -80) > ${O}_probe_$(basename $scr .py).log; tail -3 ${O}_probe_$(basename $scr .py).log;;
+    prof) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/${O}_prof -o r4 -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OLDPWD/${O}_prof.log 2>&1; cd $OLDPWD; ls ${O}_prof | head;;
+    *) echo "unknown stage $st";;
+  esac
+done
