@@ -124,12 +124,11 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
                  loop with bf16 weights, gradients rounded to bf16 and `adamw_update_bf16` (pinned against torch's
                  fused kernel in tests/test_oracle_golden.py).
     Stated tolerance. SURVEY.md §8c asks for every step within 1 % of the reference curve. That holds while the run is in
-    its early, well-conditioned phase (first 60 steps: asserted, +1e-2 abs). Later, with the loss falling from 6.1 to 1.7
-    at lr 3e-3, the trajectory is sensitive to rounding: the fp32 oracle restarted from weights perturbed by 1e-3 strays
-    up to 5.0 % from itself at single steps, and the oracle in the reference's own precision (`bf16_acts`: bf16 tensors
-    between modules) 5.5 % (1.4-2.1 % after smoothing). The engine therefore has to stay inside THAT envelope, which the
-    test measures itself on the same token stream: worst single-step deviation <= 1.25 x the bf16-path emulation's (floor
-    2 %), smoothed curve (EMA 0.2) within max(1.5 %, 1.25 x the emulation's), and the task is actually being learnt."""
+    its early, well-conditioned phase (first 60 steps: asserted, +1e-2 abs). Later, with the loss falling from 6.1 to 1.8
+    at lr 3e-3, the trajectory is sensitive to rounding: the reference's own bf16 run strays 13 % (single step) / 8.9 %
+    (smoothed) from its fp32 run, and implementations of the SAME precision differ by 4-6 % at single steps (1.4-2.8 % after
+    smoothing) among themselves. The engine has to stay inside THAT envelope - measured below between the oracle loop, its
+    bf16-activation emulation and the real reference's run on the same token stream - and the task must actually be learnt."""
     from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
     from tests import traj_stream as TS
     sd = O.init_weights(O.TINY, seed=11, bias_std=0.0, norm_jitter=0.0)
@@ -146,36 +145,43 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
     assert state.global_step == steps and len(eng) == steps
     bf = state_dtype == "bfloat16"
     ema, worst = TS.ema, TS.worst
+    if os.path.isdir("gpurun_out"):  # keep the engine's curve next to the other measurements of a GPU session
+        import numpy as np
+        np.save(os.path.join("gpurun_out", f"engine_loss_curve_{state_dtype}.npy"), np.array(eng))
     # the same loop on the oracle: bf16 state = the recipe's precision; fp32 state = fp32 master weights whose bf16 rounding
-    # the forward / backward computes with (what the engine does)
-    ref = TS.oracle_loop(bf, False, round_weights=not bf)[0]
-    emu = TS.oracle_loop(bf, True, round_weights=not bf)[0]   # the same loop in the reference's own activation precision: the sensitivity envelope
+    # the forward / backward computes with (what the engine does). `emu` = the same loop in the reference's own activation
+    # precision: the sensitivity envelope. Both curves are STORED (tests/golden/traj_oracle.npz, make_traj_oracle.py; the CPU
+    # tier re-derives their first 30 steps from the oracle): ~2.5 minutes of oracle loops that the GPU box no longer runs.
+    oc = TS.load_oracle_curves()
+    ref, emu = (list(oc[("ref_" if k == 0 else "emu_") + ("bf16" if bf else "fp32")]) for k in (0, 1))
     print("engine", [round(x, 3) for x in eng[::20]])
     print("oracle", [round(x, 3) for x in ref[::20]])
     print("bf16-path emulation", [round(x, 3) for x in emu[::20]])
     assert ref[-1] < 0.75 * ref[0], (ref[0], ref[-1])
-    w_eng, w_emu = worst(eng, ref), worst(emu, ref)
-    s_eng, s_emu = worst(ema(eng), ema(ref)), worst(ema(emu), ema(ref))
-    print(f"[parity] 200-step curve, {state_dtype} optimizer state: worst single-step deviation engine {w_eng:.4f} / bf16-path "
-          f"emulation {w_emu:.4f}; smoothed engine {s_eng:.4f} / emulation {s_emu:.4f}; first 60 steps {worst(eng[:60], ref[:60]):.4f}")
+    # ---- the envelope: how far apart the CPU realisations of this very run are among themselves - the oracle loop, the
+    # oracle loop in the reference's activation precision, and the REAL reference model on the HF / torch step
+    # (tests/golden/traj.npz, make_golden_traj.py: the fp32 leg for the fp32-state engine, the bf16 leg - bf16 parameters,
+    # bf16 autocast, bf16 AdamW - for the bf16-state engine; the oracle's pure-fp32 loop reproduces the fp32 leg to 0.15 %,
+    # tests/test_oracle_golden.py). The worst single step over 200 steps of a rounding-sensitive trajectory is an extreme-value
+    # statistic: the engine may sit 1.5 x as far from the oracle / the reference as those three sit from each other (floor
+    # 2 %); the smoothed curve 1.25 x (floor 1.5 %); the first 60 steps within 1 % (+1e-2) of the oracle and within
+    # max(1.5 %, 1.25 x the emulation's distance) of the reference's curve.
+    fx = TS.load_fixture()
+    leg = list(fx["loss_bf16"] if bf else fx["loss_fp32"])
+    pairs = ((emu, ref), (emu, leg), (ref, leg))
+    env_w = max(worst(x, y) for x, y in pairs)
+    env_s = max(worst(ema(x), ema(y)) for x, y in pairs)
+    w_ref, w_leg = worst(eng, ref), worst(eng, leg)
+    s_ref, s_leg = worst(ema(eng), ema(ref)), worst(ema(eng), ema(leg))
+    f60_ref, f60_leg = worst(eng[:60], ref[:60]), worst(eng[:60], leg[:60])
+    print(f"[parity] 200-step curve, {state_dtype} optimizer state: worst single step engine-oracle {w_ref:.4f}, engine-reference {w_leg:.4f} "
+          f"(CPU realisations among themselves {env_w:.4f}); smoothed {s_ref:.4f} / {s_leg:.4f} (envelope {env_s:.4f}); first 60 steps "
+          f"{f60_ref:.4f} / {f60_leg:.4f}")
     for a, b in zip(eng[:60], ref[:60]):
         assert abs(a - b) <= 0.01 * b + 1e-2, (a, b)
-    assert w_eng <= max(0.02, 1.25 * w_emu), (w_eng, w_emu)
-    assert s_eng <= max(0.015, 1.25 * s_emu), (s_eng, s_emu)
-    # ---- and against the REAL reference model on the HF / torch step (tests/golden/traj.npz, make_golden_traj.py): the
-    # fp32-state engine against the reference's fp32 leg, the bf16-state engine against its bf16 leg (bf16 parameters, bf16
-    # autocast, bf16 AdamW). The envelope is the oracle emulation's distance from the same fixture curve (the oracle's
-    # fp32 loop itself reproduces the fp32 leg to 0.15 %, tests/test_oracle_golden.py).
-    fx = TS.load_fixture()
-    leg = fx["loss_bf16"] if bf else fx["loss_fp32"]
-    fw_eng, fw_emu = worst(eng, leg), worst(emu, leg)
-    fs_eng, fs_emu = worst(ema(eng), ema(leg)), worst(ema(emu), ema(leg))
-    f60 = worst(eng[:60], leg[:60])
-    print(f"[parity] 200-step curve vs the reference's own {'bf16' if bf else 'fp32'} trajectory: worst single-step deviation engine "
-          f"{fw_eng:.4f} / emulation {fw_emu:.4f}; smoothed engine {fs_eng:.4f} / emulation {fs_emu:.4f}; first 60 steps {f60:.4f}")
-    assert f60 <= max(0.015, 1.25 * worst(emu[:60], leg[:60])), f60
-    assert fw_eng <= max(0.03, 1.5 * fw_emu), (fw_eng, fw_emu)
-    assert fs_eng <= max(0.02, 1.5 * fs_emu), (fs_eng, fs_emu)
+    assert f60_leg <= max(0.015, 1.25 * worst(emu[:60], leg[:60])), f60_leg
+    assert max(w_ref, w_leg) <= max(0.02, 1.5 * env_w), (w_ref, w_leg, env_w)
+    assert max(s_ref, s_leg) <= max(0.015, 1.25 * env_s), (s_ref, s_leg, env_s)
 
 
 def test_adamw_bf16_state_step_vs_oracle():

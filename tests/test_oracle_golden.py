@@ -365,3 +365,20 @@ def test_bf16_step_emulation_tracks_the_reference_bf16_trajectory():
     assert 0.5 * gap_ref <= gap_emu <= 2.0 * gap_ref, (gap_ref, gap_emu)
     for k, n in zip(fx["final_keys"], fx["final_norm_bf16"]):
         assert abs(float(p[str(k)].float().norm()) - n) <= 0.08 * n, (k, float(p[str(k)].float().norm()), n)
+
+
+def test_stored_oracle_curves_are_the_oracles():
+    """tests/golden/traj_oracle.npz (the curves the GPU loss-curve test compares the engine with) against the oracle itself:
+    the first 30 steps of every stored curve re-derived here (1e-4: thread count moves fp32 summation order), and the two
+    curves that have a counterpart in the REAL reference's run tied to it - `ref_fp32` computes with bf16-rounded weights, so
+    it sits within the weight-rounding noise of the reference's fp32 leg, and `emu_bf16` is the bf16 leg's emulation."""
+    from tests.golden.make_traj_oracle import SETTINGS
+    from tests.traj_stream import ema, load_fixture, load_oracle_curves, oracle_loop, worst
+    oc, fx = load_oracle_curves(), load_fixture()
+    assert sorted(oc) == sorted(SETTINGS) and all(len(v) == 200 for v in oc.values())
+    for name, (bf16_state, bf16_acts, round_w) in SETTINGS.items():
+        head = oracle_loop(bf16_state, bf16_acts, round_weights=round_w, steps=30)[0]
+        d = np.abs(np.array(head) - oc[name][:30]).max()
+        assert d <= 1e-4, (name, d)
+    assert worst(oc["ref_fp32"][:60], fx["loss_fp32"][:60]) <= 0.015 and worst(ema(oc["ref_fp32"]), ema(fx["loss_fp32"])) <= 0.03
+    assert worst(oc["emu_bf16"][:60], fx["loss_bf16"][:60]) <= 0.015 and worst(ema(oc["emu_bf16"]), ema(fx["loss_bf16"])) <= 0.03

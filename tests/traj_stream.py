@@ -43,6 +43,14 @@ def load_fixture():
     return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj.npz")))
 
 
+def load_oracle_curves():
+    """tests/golden/traj_oracle.npz: oracle_loop's loss curves in the four settings of the GPU loss-curve test."""
+    import os
+
+    import numpy as np
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_oracle.npz")))
+
+
 def oracle_loop(bf16_state: bool, bf16_acts: bool, round_weights: bool = False, steps: int = STEPS):
     """The oracle's restatement of the HF Trainer step (oracle/slam_oracle.py: forward_loss_grads, clip_coef,
     cosine_with_min_lr, adamw_update / adamw_update_bf16) run over the stream.

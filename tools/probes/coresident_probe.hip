@@ -1,0 +1,105 @@
+// Do workgroups of two kernels on two streams share a CU on gfx950 when the resources allow it? (round 4, VERDICT item 6:
+// root cause of the RMSNorm backward's in-step time.) A "hog" kernel stands in for the weight-gradient GEMM of the side stream
+// - one 512-thread workgroup per CU holding LDS_KB of LDS and NV VGPRs per lane for ~300 us - and a "probe" kernel of 256-thread
+// workgroups with PV VGPRs and PLDS bytes of LDS is launched on a second stream 20 us later. Every probe workgroup records the
+// wall clock at its start: if they start while the hog is still resident, the dispatcher co-schedules the two kernels.
+//   hipcc --offload-arch=gfx950 -O2 -o coresident_probe coresident_probe.hip && ./coresident_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int NV>
+__global__ __launch_bounds__(512, 1) void hog(unsigned long long ticks, unsigned long long* t_start, unsigned long long* t_end) {
+  extern __shared__ char smem[];
+  // claim NV VGPRs: a chain of NV live values that the compiler cannot fold
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x + i);
+  const unsigned long long t0 = wall_clock64();
+  if (threadIdx.x == 0) t_start[blockIdx.x] = t0;
+  smem[threadIdx.x] = (char)threadIdx.x;
+  while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = v[i] * 1.0001f + 0.5f;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  if (s == 12345.678f) t_end[blockIdx.x] = 1;  // keeps v alive
+  if (threadIdx.x == 0) t_end[blockIdx.x] = wall_clock64();
+}
+
+template <int PV, int PLDS>
+__global__ __launch_bounds__(256) void probe(unsigned long long* t_start, float* sink) {
+  __shared__ char l[PLDS > 0 ? PLDS : 4];
+  float v[PV];
+#pragma unroll
+  for (int i = 0; i < PV; ++i) v[i] = (float)(threadIdx.x * i);
+  if (threadIdx.x == 0) t_start[blockIdx.x] = wall_clock64();
+  l[threadIdx.x % (PLDS > 0 ? PLDS : 4)] = 1;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 200) {  // ~2 us of life
+#pragma unroll
+    for (int i = 0; i < PV; ++i) v[i] = v[i] * 1.0001f + 0.5f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PV; ++i) s += v[i];
+  if (s == 12345.678f) sink[0] = s + l[0];
+}
+
+template <int NV, int PV, int PLDS>
+void run(int lds_kb, int hog_blocks, const char* label) {
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  const int NP = 2048;
+  unsigned long long *hs, *he, *ps;
+  float* sink;
+  CK(hipMalloc(&hs, 256 * 8)); CK(hipMalloc(&he, 256 * 8)); CK(hipMalloc(&ps, NP * 8)); CK(hipMalloc(&sink, 64));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hog<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+  hipFuncAttributes fa, fb;
+  CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&hog<NV>)));
+  CK(hipFuncGetAttributes(&fb, reinterpret_cast<const void*>(&probe<PV, PLDS>)));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(ps, 0, NP * 8));
+    CK(hipDeviceSynchronize());
+    hog<NV><<<hog_blocks, 512, lds_kb * 1024, s1>>>(30000ull /* 300 us at 100 MHz */, hs, he);
+    // ~20 us later on the other stream
+    hipEvent_t e; CK(hipEventCreate(&e)); CK(hipEventRecord(e, s1));
+    for (volatile int spin = 0; spin < 20000; ++spin) {}
+    probe<PV, PLDS><<<NP, 256, 0, s2>>>(ps, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventDestroy(e));
+  }
+  std::vector<unsigned long long> a(hog_blocks), b(hog_blocks), c(NP);
+  CK(hipMemcpy(a.data(), hs, hog_blocks * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), he, hog_blocks * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(c.data(), ps, NP * 8, hipMemcpyDeviceToHost));
+  const unsigned long long h0 = *std::min_element(a.begin(), a.end()), h1 = *std::min_element(b.begin(), b.end());
+  int during = 0;
+  std::sort(c.begin(), c.end());
+  for (auto t : c) during += (t < h1);
+  printf("%-46s hog %3d blocks x (%3d KB LDS, %3d VGPRs) | probe (%3d VGPRs, %5d B LDS): %4d of %d probe blocks started while the hog was resident; "
+         "first probe +%.1f us, median +%.1f us, last +%.1f us after the hog's start (hog lasts %.1f us)\n",
+         label, hog_blocks, lds_kb, fa.numRegs, fb.numRegs, (int)fb.sharedSizeBytes, during, NP, (c.front() - (double)h0) / 100.0,
+         (c[NP / 2] - (double)h0) / 100.0, (c.back() - (double)h0) / 100.0, (h1 - (double)h0) / 100.0);
+  CK(hipFree(hs)); CK(hipFree(he)); CK(hipFree(ps)); CK(hipFree(sink));
+  CK(hipStreamDestroy(s1)); CK(hipStreamDestroy(s2));
+}
+
+int main() {
+  run<8, 8, 0>(0, 256, "light hog, light probe (control)");
+  run<218, 8, 0>(128, 256, "GEMM-sized hog, tiny probe");
+  run<218, 40, 4096>(128, 256, "GEMM-sized hog, lean-norm-sized probe");
+  run<218, 120, 16384>(128, 256, "GEMM-sized hog, fat-norm-sized probe");
+  run<218, 40, 4096>(64, 256, "64 KB hog, lean probe");
+  run<100, 40, 4096>(128, 256, "128 KB / ~128-VGPR hog, lean probe");
+  run<218, 40, 4096>(128, 152, "152-block GEMM-sized hog, lean probe");
+  return 0;
+}
