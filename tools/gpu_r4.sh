@@ -12,7 +12,8 @@ O=gpurun_out/${tag}
 for st in "$@"; do
   kind=${st%%:*}; rest=${st#*:}; [ "$rest" = "$st" ] && rest=""
   case $kind in
-    t) (timeout ${T_TIMEOUT:-900} python -m pytest tests -m gpu -x -q -k "$rest" 2>&1 | tail -${T_TAIL:-25}) > ${O}_t_$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40).log; tail -4 ${O}_t_*.log | tail -6;;
+    t) L=${O}_t_$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40).log
+       (timeout ${T_TIMEOUT:-900} python -m pytest tests -m gpu -x -q -s -k "$rest" 2>&1 | grep -E "parity|passed|failed|Error|error|assert" | tail -${T_TAIL:-40}) > $L; tail -n 3 $L;;
     full) (timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 2>&1 | tail -60) > ${O}_pytest.log; tail -5 ${O}_pytest.log;;
     smoke) (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3) > ${O}_smoke.log; tail -1 ${O}_smoke.log;;
     b|q) name=${rest%%:*}; envs=${rest#*:}; [ "$envs" = "$rest" ] && envs=""
