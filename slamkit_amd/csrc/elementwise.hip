@@ -1061,7 +1061,7 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
 }
 
 // rows of the per-block weight-gradient slab the callers reserve: the larger of the two kernels' grids
-static int g_norm_bwd_lean = 1, g_norm_bwd_lean_blocks = 1024;
+static int g_norm_bwd_lean = 0, g_norm_bwd_lean_blocks = 1024;  // lean: measured equal alone, no faster beside the GEMMs
 void norm_bwd_tune(int lean, int blocks) {
   if (lean >= 0) g_norm_bwd_lean = lean;
   if (blocks > 0) g_norm_bwd_lean_blocks = blocks > 2048 ? 2048 : blocks;

@@ -213,7 +213,7 @@ def test_rmsnorm_fwd_bwd(M, H, lean):
     try:
         _rmsnorm_fwd_bwd(M, H)
     finally:
-        lib().slam_set_option(None, b"norm_bwd_lean", 1)
+        lib().slam_set_option(None, b"norm_bwd_lean", 0)
 
 
 def test_rmsnorm_bwd_lean_is_bit_reproducible_and_grid_independent_in_dx():
@@ -225,6 +225,7 @@ def test_rmsnorm_bwd_lean_is_bit_reproducible_and_grid_independent_in_dx():
     rstd = torch.rsqrt(x.to(torch.bfloat16).float().pow(2).mean(-1) + 1e-6).cuda()
     ws = torch.empty(lib().slam_op_rmsnorm_bwd_workspace(M, H) // 4 + 16, dtype=torch.float32, device="cuda")
     outs = []
+    assert lib().slam_set_option(None, b"norm_bwd_lean", 1) == 0
     try:
         for blocks in (1024, 1024, 64, 187):
             assert lib().slam_set_option(None, b"norm_bwd_blocks", blocks) == 0
@@ -235,6 +236,7 @@ def test_rmsnorm_bwd_lean_is_bit_reproducible_and_grid_independent_in_dx():
             outs.append((dx.clone(), dw.clone()))
     finally:
         lib().slam_set_option(None, b"norm_bwd_blocks", 1024)
+        lib().slam_set_option(None, b"norm_bwd_lean", 0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][0], outs[3][0])
     check("dw across grids", outs[2][1], outs[0][1], 1e-5)

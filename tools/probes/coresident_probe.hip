@@ -93,7 +93,92 @@ void run(int lds_kb, int hog_blocks, const char* label) {
   CK(hipStreamDestroy(s1)); CK(hipStreamDestroy(s2));
 }
 
+// ---- part 2: does a CO-RESIDENT memory-bound kernel get bandwidth? A streaming kernel shaped like the lean RMSNorm backward
+// (256 threads, <= 64 VGPRs, no LDS to speak of: three 16-byte loads and one store per lane per row) is timed alone, beside the
+// ALU-only hog, and beside a hog that ALSO streams operands through the vector-memory path the way the GEMM's LDS-DMA does
+// (every wave loads 4 x 16 B per lane per ~1 us from a 16 MB, cache-resident buffer: ~50 GB/s per CU).
+__global__ __launch_bounds__(256, 8) void stream_probe(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c,
+                                                       uint4* __restrict__ o, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 x = a[i], y = b[i], z = c[i];
+    o[i] = make_uint4(x.x ^ y.x ^ z.x, x.y + y.y + z.y, x.z ^ y.z ^ z.z, x.w + y.w + z.w);
+  }
+}
+template <int NV>
+__global__ __launch_bounds__(512, 1) void hog_mem(unsigned long long ticks, const uint4* __restrict__ src, size_t n16, float* sink) {
+  extern __shared__ char smem[];
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x + i);
+  const unsigned long long t0 = wall_clock64();
+  size_t at = ((size_t)blockIdx.x * 512 + threadIdx.x) % n16;
+  unsigned acc = 0;
+  while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // 4 x 16 B per lane per round
+      const uint4 q = src[at];
+      acc += q.x ^ q.w;
+      at += 512 * 251;
+      if (at >= n16) at -= n16;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = v[i] * 1.0001f + 0.5f;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  float s = (float)acc;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  smem[threadIdx.x] = (char)s;
+  if (s == 12345.678f) sink[0] = s;
+}
+
+void part2() {
+  const size_t bytes = 8192ull * 896 * 2, n16 = bytes / 16;  // one [8192][896] bf16 array
+  uint4 *a, *b, *c, *o, *src;
+  float* sink;
+  unsigned long long *hs, *he;
+  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&c, bytes)); CK(hipMalloc(&o, bytes));
+  CK(hipMalloc(&src, 16 << 20)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&hs, 256 * 8)); CK(hipMalloc(&he, 256 * 8));
+  CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes)); CK(hipMemset(c, 3, bytes)); CK(hipMemset(src, 5, 16 << 20));
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hog<218>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hog_mem<200>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  hipFuncAttributes fm;
+  CK(hipFuncGetAttributes(&fm, reinterpret_cast<const void*>(&hog_mem<200>)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int blocks : {256, 152}) {
+    for (int mode = 0; mode < 3; ++mode) {
+      float best = 1e9f, sum = 0.f;
+      const int reps = 7;
+      for (int r = 0; r < reps; ++r) {
+        CK(hipDeviceSynchronize());
+        if (mode == 1) hog<218><<<blocks, 512, 128 * 1024, s1>>>(30000ull, hs, he);
+        if (mode == 2) hog_mem<200><<<blocks, 512, 128 * 1024, s1>>>(30000ull, src, (size_t)(16 << 20) / 16, sink);
+        for (volatile int spin = 0; spin < 20000; ++spin) {}
+        CK(hipEventRecord(e0, s2));
+        stream_probe<<<2048, 256, 0, s2>>>(a, b, c, o, n16);
+        CK(hipEventRecord(e1, s2));
+        CK(hipDeviceSynchronize());
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+        sum += ms;
+      }
+      printf("streaming kernel (58.7 MB: 3 reads + 1 write of [8192][896] bf16) %-48s best %.1f us, mean %.1f us -> %.0f GB/s\n",
+             mode == 0 ? "alone" : mode == 1 ? (blocks == 256 ? "beside 256 ALU-only GEMM-sized blocks" : "beside 152 ALU-only GEMM-sized blocks")
+                                             : (blocks == 256 ? "beside 256 GEMM-sized blocks that stream loads" : "beside 152 GEMM-sized blocks that stream loads"),
+             best * 1e3, sum / reps * 1e3, 4.0 * bytes / (best * 1e-3) / 1e9);
+      if (mode == 0 && blocks != 256) break;
+    }
+  }
+  printf("(hog_mem: %d VGPRs)\n", fm.numRegs);
+}
+
 int main() {
+  part2();
   run<8, 8, 0>(0, 256, "light hog, light probe (control)");
   run<218, 8, 0>(128, 256, "GEMM-sized hog, tiny probe");
   run<218, 40, 4096>(128, 256, "GEMM-sized hog, lean-norm-sized probe");

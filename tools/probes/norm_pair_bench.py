@@ -78,7 +78,7 @@ def case(M, H, bgN, bgK, label):
         a, _ = timed(False)
         b, g = timed(True)
         say(f"| {'lean (<= 64 VGPR)' if lean else 'register-pipelined (144+ VGPR)'} | {blocks or 'min(M/16, 512)'} | {a:.1f} | {nbytes / a / 1e3:.0f} | {b:.1f} | {b / a:.2f}x | {g:.1f} |")
-    lib.slam_set_option(None, b"norm_bwd_lean", 1)
+    lib.slam_set_option(None, b"norm_bwd_lean", 0)
     lib.slam_set_option(None, b"norm_bwd_blocks", 1024)
     lib.slam_set_option(None, b"gemm_tn224", 1)
     lib.slam_set_option(None, b"gemm_tn224_max_split", 16)
