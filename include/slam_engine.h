@@ -213,9 +213,7 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
  * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "bwd_wgrad_stream" (default
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
- * reported bucket range, and the end of the call). "bwd_wgrad_small_stream" = 1: the short weight-gradient launches (Wo,
- * Wqkv, head, embedding) get a third engine-owned stream with their own slab workspace. "gemm_256_shared_blocks" = N: grid of
- * the persistent 256 x 256 launches inside slam_backward (0 = one block per CU). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
+ * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",
  * "gemm_256_dswiglu", "gemm_256_persist", "gemm_tn224", "gemm_tn_balanced", "gemm_group_rows" select kernels. */
 int slam_set_option(SlamEngine* h, const char* key, int64_t value);
 

@@ -96,17 +96,11 @@ struct SlamEngine {
   bool time_families = false;
   std::vector<hipEvent_t> fam_ev;                 // pool, reused step after step
   std::vector<std::pair<int, size_t>> fam_marks;  // (family id, index of the pair's first event)
-  // "bwd_wgrad_small_stream": the short weight-gradient launches (Wo, Wqkv, head, embedding: the balanced 128 x 128 kernel and
-  // its slab reduces) get a stream of their own, so that they are not queued behind the two long 256 x 224 launches of
-  // their layer; the slab workspace belongs to that stream alone (the long launches run unsplit: no slabs)
-  int wgrad_small_stream = 0;
-  hipStream_t wside2 = nullptr;
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
   ~SlamEngine() {
     if (wside) { (void)hipStreamSynchronize(wside); (void)hipStreamDestroy(wside); }
-    if (wside2) { (void)hipStreamSynchronize(wside2); (void)hipStreamDestroy(wside2); }
     for (hipEvent_t e : fam_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_w) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
@@ -125,7 +119,7 @@ struct SlamEngine {
   bool time_param_waits = false;   // "time_param_waits": bracket the parameter waits of a forward with timing events (slam_param_wait_ms)
   float* nlse = nullptr;
   float *cosq = nullptr, *sinq = nullptr;  // the query heads' RoPE tables: cos / sin times head_dim^-0.5 * log2(e)
-  float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *gemm_ws2, *part_ws, *scal;
+  float *rstdf, *row_loss, *dsum, *dkv_part, *cosb, *sinb, *gemm_ws, *part_ws, *scal;
   float *ln_part, *bias_part;  // per-layer partial slabs: [2L][nb_ln][H], [L][nb_cs][QKV]
   size_t ln_ps = 0, bias_ps = 0;
   size_t gemm_ws_bytes = 0;
@@ -219,7 +213,6 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->attn_plan_buf = c.take<int>(attn_plan_ints((int)M));
   e->gemm_ws_bytes = max_gemm_ws(e, (int)M);
   e->gemm_ws = c.take<float>(e->gemm_ws_bytes / sizeof(float));
-  e->gemm_ws2 = c.take<float>(e->gemm_ws_bytes / sizeof(float));  // "bwd_wgrad_small_stream": the short launches' own slabs
   size_t part = (size_t)rmsnorm_bwd_blocks((int)M) * H;
   size_t part2 = (size_t)colsum_blocks((int)M) * e->QKV;
   if (part2 > part) part = part2;
@@ -317,7 +310,7 @@ int ensure_side(SlamEngine* h) {
   return 0;
 }
 int ensure_wside(SlamEngine* h) {
-  if (h->wside && h->wside_cus_applied == h->wside_cus && (!h->wgrad_small_stream || h->wside2)) return 0;
+  if (h->wside && h->wside_cus_applied == h->wside_cus) return 0;
   hipError_t e = hipSuccess;
   if (h->wside && h->wside_cus_applied != h->wside_cus) {  // the mask changed: replace the stream
     (void)hipStreamSynchronize(h->wside);
@@ -336,12 +329,8 @@ int ensure_wside(SlamEngine* h) {
   }
   if (e != hipSuccess) return (int)e;
   h->wside_cus_applied = h->wside_cus;
-  if (h->wgrad_small_stream && !h->wside2) {
-    e = hipStreamCreateWithFlags(&h->wside2, hipStreamNonBlocking);
-    if (e != hipSuccess) return (int)e;
-  }
   if (h->ev_w.empty()) {
-    h->ev_w.resize((size_t)(h->d.n_layers + 2) * 8);
+    h->ev_w.resize((size_t)(h->d.n_layers + 1) * 8);
     for (auto& ev : h->ev_w) {
       e = hipEventCreateWithFlags(&ev, sync_event_flags());
       if (e != hipSuccess) return (int)e;
@@ -568,10 +557,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     h->time_gateup = value != 0;
     return SLAM_OK;
   }
-  if (!strcmp(key, "norm_bwd_lean")) { norm_bwd_tune(value != 0, 0); return SLAM_OK; }      // process-wide (kernel selection)
-  if (!strcmp(key, "norm_bwd_blocks")) { norm_bwd_tune(-1, (int)value); return SLAM_OK; }
   if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
-  if (!strcmp(key, "bwd_wgrad_small_stream") && h) { h->wgrad_small_stream = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
@@ -707,15 +693,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   //    needs its work as early as it can have it.
   const bool two = h->wgrad_stream != 0;
   if (two) CK(ensure_wside(h));
-  const bool three = two && h->wgrad_small_stream != 0 && h->wside2 != nullptr;
   GemmTuneScope tune_scope(&h->gemm_tune);
   struct SharedGuard {  // dgrad launches of this call may plan for a GPU they share with the wgrad stream
     GemmTune* t;
     SharedGuard(GemmTune* t_, int on) : t(t_) { t->shared = on; }
     ~SharedGuard() { t->shared = 0; }
   } shared_guard(&h->gemm_tune, two ? 1 : 0);
-  hipStream_t ws = two ? h->wside : st;       // the long weight-gradient launches (Wd, Wgu)
-  hipStream_t ws2 = three ? h->wside2 : ws;   // the short ones (Wo, Wqkv, head, embedding); owns the second slab workspace
+  hipStream_t ws = two ? h->wside : st;
   int ev_used = 0;
   auto edge = [&](hipStream_t from, hipStream_t to) -> int {  // `to` continues after everything enqueued on `from` so far
     if (from == to) return 0;
@@ -727,16 +711,15 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   };
   auto fork = [&]() -> int { return two ? edge(st, ws) : 0; };
   // dW (+)= a^T b on a weight-gradient stream
-  auto wgrad = [&](int fam, bool small, const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
-    hipStream_t t = small ? ws2 : ws;
-    if (two) { if (int r = edge(st, t)) return r; }
-    const int slot = fam_begin(h, fam, t);
-    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, (small && three) ? h->gemm_ws2 : h->gemm_ws, h->gemm_ws_bytes, t, two ? 1 : 0);
-    fam_end(h, slot, t);
+  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
+    if (int r = fork()) return r;
+    const int slot = fam_begin(h, fam, ws);
+    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
+    fam_end(h, slot, ws);
     return r;
   };
 
-  CK(wgrad(F_HEAD_WGRAD, true, h->dlogits, h->hf, G + h->off_embed, VP, H));
+  CK(wgrad(F_HEAD_WGRAD, h->dlogits, h->hf, G + h->off_embed, VP, H));
   TK(F_HEAD_DGRAD, st, dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
   TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
@@ -750,7 +733,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     bf16_t* dh2 = h->hs[l + 1];                              // grad wrt hmid[l]: hs[l+1] was last read by the norm backward above it
     bf16_t* dqkv = l + 1 < L ? h->la[l + 1].qkv : h->dqkv;   // layer l+1's q|k|v were last read by its attention backward
     // MLP
-    CK(wgrad(F_WD_WGRAD, false, dh, a.act, G + o.wd, H, I));
+    CK(wgrad(F_WD_WGRAD, dh, a.act, G + o.wd, H, I));
     {
       const int slot = fam_begin(h, F_DOWN_DGRAD, st);
       if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
@@ -761,16 +744,16 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       }
       fam_end(h, slot, st);
     }
-    CK(wgrad(F_WGU_WGRAD, false, a.gu, a.x2, G + o.wgu, 2 * I, H));
+    CK(wgrad(F_WGU_WGRAD, a.gu, a.x2, G + o.wgu, 2 * I, H));
     TK(F_GATEUP_DGRAD, st, dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(wgrad(F_WO_WGRAD, true, dh2, a.o, G + o.wo, H, HD));
+    CK(wgrad(F_WO_WGRAD, dh2, a.o, G + o.wo, H, HD));
     TK(F_O_DGRAD, st, dgrad(dh2, o.wo, h->d_o, H, HD));
     TK(F_ATTN_BWD, st, attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(wgrad(F_WQKV_WGRAD, true, dqkv, a.x1, G + o.wqkv, h->QKV, H));
+    CK(wgrad(F_WQKV_WGRAD, dqkv, a.x1, G + o.wqkv, h->QKV, H));
     TK(F_QKV_DGRAD, st, dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
     dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
     TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
@@ -780,18 +763,16 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     if (l == 0 || boundary) {
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
-      const int nbl = rmsnorm_bwd_rows(M, H), nbc = colsum_blocks(M);
+      const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st));
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st));
       CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st));
       fin_hi = l;
     }
     if (boundary) {
-      // the side streams are in order: the last launch of layer l on each covers every wgrad of the range. Order the long
-      // stream after the finish kernels above and after the short stream as well, and hand IT to the consumer
-      // (slam_bucket_stream): main does not stall here.
+      // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
+      // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
       CK(fork());
-      if (three) CK(edge(ws2, ws));
       h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
       h->bucket_stream = nullptr;
@@ -800,22 +781,19 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   }
   // gather-side embedding gradient (padding_idx row suppressed): small vocabularies run it as
   // dE += onehot(ids)^T dh0 on the wgrad GEMM, large ones as a token-ordered scatter; both deterministic
-  // (on the stream of the head's weight gradient: ordered after its contribution to the same rows)
-  if (two) CK(edge(st, ws2));
+  // (on the wgrad stream: ordered after the head's contribution to the same rows)
+  CK(fork());
   {
-    const int slot = fam_begin(h, F_EMBED_WGRAD, ws2);
+    const int slot = fam_begin(h, F_EMBED_WGRAD, ws);
     if (VP == VPAD_SMALL) {
-      CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws2));
-      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, three ? h->gemm_ws2 : h->gemm_ws, h->gemm_ws_bytes, ws2, two ? 1 : 0));
+      CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
+      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
     } else {
-      CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws2));
+      CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
     }
-    fam_end(h, slot, ws2);
+    fam_end(h, slot, ws);
   }
-  if (two) {  // join: everything after slam_backward on `stream` sees complete gradients
-    CK(edge(ws, st));
-    if (three) CK(edge(ws2, st));
-  }
+  if (two) CK(edge(ws, st));  // join: everything after slam_backward on `stream` sees complete gradients
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   return SLAM_OK;

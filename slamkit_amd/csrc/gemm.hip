@@ -54,8 +54,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
-      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_256_shared_blocks", &t->g256_shared_blocks, 0, 256}};
+      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -1566,11 +1565,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
   const int tiles = a.tiles_r * a.tiles_c;
-  // shared mode (the engine's backward: a weight-gradient launch of 76 / 152 one-per-CU blocks runs beside this one): a grid
-  // smaller than the chip leaves those blocks CUs of their own instead of queueing them behind 256 resident blocks
-  int grid = cus;
-  if (T().shared && T().g256_shared_blocks >= 8) grid = std::min(cus, T().g256_shared_blocks & ~7);
-  if (T().g256_persist && tiles > grid && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<grid, 512, 8 * 128 * 128, st>>>(a);
+  if (T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
   else gemm_nt_256_kernel<false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }

@@ -18,7 +18,6 @@ struct GemmTune {
   int nt_store = 0;
   int g256 = 1;                 // 256 x 256 NT kernel: 1 = when its fill criterion holds, 0 = never, 2 = whenever the shape allows
   int g256_dswiglu = 1, g256_persist = 1;
-  int g256_shared_blocks = 0;   // persistent 256 x 256 launches in shared mode: grid size (multiple of 8; 0 = every CU)
   // late start (10-ns ticks) of the persistent blocks that have a tile of slack (plain / SwiGLU forward; SwiGLU backward):
   // their store bursts fall under the other blocks' K loops. Same box, interleaved: 24.88 / 24.95 ms vs 25.05 / 25.17 / 25.39
   int g256_stagger = 1200, g256_stagger_dswiglu = 1200;
@@ -74,9 +73,7 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
 
 // elementwise.hip
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
-int rmsnorm_bwd_blocks(int M);          // slab rows to reserve per [M][H] instance (capacity)
-int rmsnorm_bwd_rows(int M, int H);     // slab rows the next rmsnorm_bwd launch of this shape writes
-void norm_bwd_tune(int lean, int blocks);  // "norm_bwd_lean" (0 / 1; -1 keeps), "norm_bwd_blocks" (grid of the lean kernel; 0 keeps)
+int rmsnorm_bwd_blocks(int M);
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st);
 int colsum_blocks(int M);

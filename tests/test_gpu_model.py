@@ -202,10 +202,9 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
     cfg, sd, sd_bf, m = tiny
     ids, lab = (torch.from_numpy(golden_npz[k]) for k in ("pad_ids", "pad_labels"))
 
-    def run(two, three=0, timed=0):
+    def run(two, timed=0):
         m.engine.set_option("bwd_wgrad_stream", two)
-        m.engine.set_option("bwd_wgrad_small_stream", three)  # the short weight gradients on a third stream (own slab workspace)
-        m.engine.set_option("time_families", timed)           # timing-event pairs around every launch must not change a bit
+        m.engine.set_option("time_families", timed)  # timing-event pairs around every launch must not change a bit
         m.zero_grad()
         got = []
         for rep in range(3):  # back-to-back backwards: the side stream of one must not run into the next
@@ -218,7 +217,7 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
         m.engine.set_option("gemm_tn_bal_bg_max_split", 8)  # same split plans on both paths
         m.engine.set_option("gemm_tn224_bg_min_m", 1 << 30)
         m.engine.set_option("gemm_nt224", 0)
-        outs = [run(0), run(1), run(1), run(1, 1), run(1, 1, 1)]
+        outs = [run(0), run(1), run(1), run(1, 1)]
         assert all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
         assert all(outs[0][1] == o[1] for o in outs[1:])
         fam = m.engine.family_ms()  # the last forward + backward, in launch order
@@ -233,7 +232,6 @@ def test_wgrad_side_stream_is_bit_identical(tiny, golden_npz):
         assert rel_err(dflt[0], outs[0][0]) <= 1e-5
     finally:
         m.engine.set_option("bwd_wgrad_stream", 1)
-        m.engine.set_option("bwd_wgrad_small_stream", 0)
         m.engine.set_option("time_families", 0)
         m.engine.set_option("gemm_tn_bal_bg_max_split", 4)
         m.engine.set_option("gemm_tn224_bg_min_m", 4096)
