@@ -196,6 +196,12 @@ const char* slam_family_name(int32_t family);
  * grads[offset, offset + count) (fp32) into a bf16 communication buffer (round-to-nearest-even) / widen a reduced bf16 range
  * back into the fp32 gradient buffer. offset and count are multiples of 4; dst / src point at the range's first element. */
 int slam_pack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, void* dst_bf16, slam_stream_t stream);
+/* ... or no pack pass at all: grads_bf16 = a bf16 buffer of slam_param_count() elements (NULL = off). The NEXT slam_backward
+ * stores every FINAL gradient value there as well, rounded to nearest even, from the kernels that store the fp32 value (weight-
+ * gradient tile epilogues, slab reduces, norm / bias finish) - bit-identical to slam_pack_grads_bf16 over the same range, for
+ * 2 B/param of extra stores instead of a 6 B/param pass beside a backward that has no idle bandwidth. A range reported through
+ * slam_bucket_cb is complete in the image as well. Consumed by that one backward (the last micro-batch of a step). */
+int slam_set_grad_image(SlamEngine* h, void* grads_bf16);
 int slam_unpack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, const void* src_bf16, slam_stream_t stream);
 /* With slam_set_option(h, "overlap_adamw", 1), slam_adamw_step returns after forking the update onto an engine-owned side
  * stream in per-layer chunks; the next slam_forward waits for chunk l right before layer l and every other entry point
@@ -230,6 +236,10 @@ int slam_op_gemm_nn(const void* dY, const void* W, void* dX, const void* resid, 
 size_t slam_op_gemm_tn_workspace(int M, int N, int K);
 int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, int M, int N, int K, float* ws,
                     slam_stream_t s);
+/* the same weight-gradient GEMM, also writing the bf16 image of every final dW value (slam_set_grad_image's mechanism);
+ * background != 0 selects the plans slam_backward uses on its weight-gradient stream */
+int slam_op_gemm_tn_image(const void* dY, const void* X, float* dW, void* dW_bf16, int accumulate, int M, int N, int K,
+                          float* ws, int background, slam_stream_t s);
 int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s);
 size_t slam_op_rmsnorm_bwd_workspace(int M, int H);
 int slam_op_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,

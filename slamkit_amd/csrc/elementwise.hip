@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // blockIdx.y selects one of several equally shaped instances (per-layer partial slabs finished together).
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nb, int N,
                                                             float* __restrict__ out, int accumulate,
-                                                            size_t part_stride, size_t out_stride) {
+                                                            size_t part_stride, size_t out_stride, bf16_t* __restrict__ img) {
   __shared__ float red[16][17];
   part += (size_t)blockIdx.y * part_stride;
   out += (size_t)blockIdx.y * out_stride;
+  if (img) img += (size_t)blockIdx.y * out_stride;
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cl];
-    out[c] = (accumulate ? out[c] : 0.f) + t;
+    const float o = (accumulate ? out[c] : 0.f) + t;
+    out[c] = o;
+    if (img) img[c] = f32_to_bf16(o);
   }
 }
 
@@ -938,7 +941,7 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
 int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st) {
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img) {
   if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   switch ((H / 8 + 63) / 64) {
@@ -947,14 +950,14 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
     case 3: rmsnorm_bwd_kernel<3><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
     default: rmsnorm_bwd_kernel<4><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
   }
-  if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0);  // dw == null: caller finishes later
+  if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0, dw_img);  // dw == null: caller finishes later
   LAUNCH_RET();
 }
 // finish `count` equally shaped partial slabs in one launch: out[i] (+)= column sums of part[i]
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
-                       int accumulate, hipStream_t st) {
+                       int accumulate, hipStream_t st, bf16_t* img) {
   if (count <= 0) return 0;
-  colsum_finish_kernel<<<dim3((N + 15) / 16, count), 256, 0, st>>>(part, nb, N, out, accumulate, part_stride, out_stride);
+  colsum_finish_kernel<<<dim3((N + 15) / 16, count), 256, 0, st>>>(part, nb, N, out, accumulate, part_stride, out_stride, img);
   LAUNCH_RET();
 }
 
@@ -965,7 +968,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   int nb = colsum_blocks(M);
   dim3 grid((N / 8 + 15) / 16, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
-  if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0);
+  if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0, nullptr);
   LAUNCH_RET();
 }
 

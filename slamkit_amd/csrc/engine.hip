@@ -67,6 +67,7 @@ struct SlamEngine {
   // engine-owned side stream; the next forward waits for chunk l right before layer l, so the HBM-bound update of
   // the later layers runs under the MFMA-bound first layers of the next step
   bool overwrite_next = false;  // "grad_overwrite_next": the next backward stores gradients instead of adding to them
+  bf16_t* grad_img = nullptr;   // slam_set_grad_image: the next backward also writes every final gradient value there, as bf16
   int overlap_adamw = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr;
@@ -680,6 +681,11 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // zeroing pass (4 B/param written by AdamW + 4 B/param re-read by the wgrad epilogues)
   const int acc = h->overwrite_next ? 0 : 1;
   h->overwrite_next = false;
+  // bf16 communication image of the gradients (slam_set_grad_image): written by the SAME kernels that store the final fp32
+  // values (unsplit weight-gradient tiles, slab reduces, the norm / bias finish kernel) - no conversion pass over the buffer
+  bf16_t* const IMG = h->grad_img;
+  h->grad_img = nullptr;
+  auto img = [&](int64_t off) -> bf16_t* { return IMG ? IMG + off : nullptr; };
 
   // weight-gradient launches: on the main stream, or (bwd_wgrad_stream) on the side stream `ws` behind an event that the
   // main stream records once their operands exist. Every cross-stream edge costs the recording AND the waiting stream a
@@ -711,18 +717,18 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   };
   auto fork = [&]() -> int { return two ? edge(st, ws) : 0; };
   // dW (+)= a^T b on a weight-gradient stream
-  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k) -> int {
+  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k, bf16_t* gi) -> int {
     if (int r = fork()) return r;
     const int slot = fam_begin(h, fam, ws);
-    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0);
+    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, gi);
     fam_end(h, slot, ws);
     return r;
   };
 
-  CK(wgrad(F_HEAD_WGRAD, h->dlogits, h->hf, G + h->off_embed, VP, H));
+  CK(wgrad(F_HEAD_WGRAD, h->dlogits, h->hf, G + h->off_embed, VP, H, nullptr));  // not final: the gather side adds to it below
   TK(F_HEAD_DGRAD, st, dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
-  TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st));
+  TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st, img(h->off_norm)));
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
   int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
@@ -733,7 +739,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     bf16_t* dh2 = h->hs[l + 1];                              // grad wrt hmid[l]: hs[l+1] was last read by the norm backward above it
     bf16_t* dqkv = l + 1 < L ? h->la[l + 1].qkv : h->dqkv;   // layer l+1's q|k|v were last read by its attention backward
     // MLP
-    CK(wgrad(F_WD_WGRAD, dh, a.act, G + o.wd, H, I));
+    CK(wgrad(F_WD_WGRAD, dh, a.act, G + o.wd, H, I, img(o.wd)));
     {
       const int slot = fam_begin(h, F_DOWN_DGRAD, st);
       if (Pt && h->fuse_dswiglu && (I % 128 == 0) && (H % 64 == 0)) {
@@ -744,16 +750,16 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       }
       fam_end(h, slot, st);
     }
-    CK(wgrad(F_WGU_WGRAD, a.gu, a.x2, G + o.wgu, 2 * I, H));
+    CK(wgrad(F_WGU_WGRAD, a.gu, a.x2, G + o.wgu, 2 * I, H, img(o.wgu)));
     TK(F_GATEUP_DGRAD, st, dgrad(a.gu, o.wgu, h->dx, 2 * I, H));
     TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, a.hmid, P + o.ln2, a.rstd2, dh, dh2, nullptr, 1, h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, M, H, st));
     // attention
-    CK(wgrad(F_WO_WGRAD, dh2, a.o, G + o.wo, H, HD));
+    CK(wgrad(F_WO_WGRAD, dh2, a.o, G + o.wo, H, HD, img(o.wo)));
     TK(F_O_DGRAD, st, dgrad(dh2, o.wo, h->d_o, H, HD));
     TK(F_ATTN_BWD, st, attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
     CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(wgrad(F_WQKV_WGRAD, dqkv, a.x1, G + o.wqkv, h->QKV, H));
+    CK(wgrad(F_WQKV_WGRAD, dqkv, a.x1, G + o.wqkv, h->QKV, H, img(o.wqkv)));
     TK(F_QKV_DGRAD, st, dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
     dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
     TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
@@ -764,9 +770,9 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
       const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st));
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st));
-      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st));
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st, img(o.ln1)));
+      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st, img(o.ln2)));
+      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st, img(o.bqkv)));
       fin_hi = l;
     }
     if (boundary) {
@@ -787,9 +793,12 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     const int slot = fam_begin(h, F_EMBED_WGRAD, ws);
     if (VP == VPAD_SMALL) {
       CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
-      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0));
+      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, img(h->off_embed)));
     } else {
       CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
+      // the scatter only touches the rows that occur in the batch (the others keep the head's contribution): this one tensor
+      // gets its image from a conversion pass
+      if (IMG) CK(f32_to_bf16(G + h->off_embed, IMG + h->off_embed, (size_t)VP * H, ws));
     }
     fam_end(h, slot, ws);
   }
@@ -1011,6 +1020,11 @@ int slam_pack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, void* dst
   if (count) CK(f32_to_bf16(h->grads + offset, (bf16_t*)dst_bf16, (size_t)count, (hipStream_t)stream));
   return SLAM_OK;
 }
+int slam_set_grad_image(SlamEngine* h, void* grads_bf16) {
+  if (!h) return SLAM_EINVAL;
+  h->grad_img = (bf16_t*)grads_bf16;
+  return SLAM_OK;
+}
 int slam_unpack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, const void* src_bf16, slam_stream_t stream) {
   if (!h || !src_bf16 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3)) return SLAM_EINVAL;
   if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
@@ -1077,6 +1091,11 @@ int slam_op_gemm_tn(const void* dY, const void* X, float* dW, int accumulate, in
   static size_t cap = 0;
   if (cm != M || cn != N || ck != K) { cap = gemm_tn_workspace_bytes(M, N, K); cm = M; cn = N; ck = K; }
   return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, cap, (hipStream_t)s);
+}
+int slam_op_gemm_tn_image(const void* dY, const void* X, float* dW, void* dW_bf16, int accumulate, int M, int N, int K, float* ws,
+                          int background, slam_stream_t s) {
+  const size_t cap = gemm_tn_workspace_bytes(M, N, K);
+  return gemm_tn((const bf16_t*)dY, (const bf16_t*)X, dW, accumulate, M, N, K, N, K, ws, cap, (hipStream_t)s, background, (bf16_t*)dW_bf16);
 }
 int slam_op_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, slam_stream_t s) {
   return rmsnorm_fwd((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, M, H, eps, (hipStream_t)s);

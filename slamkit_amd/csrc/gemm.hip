@@ -937,6 +937,7 @@ struct BalArgs {
   int T_A, S_A, per_A, T_B, S_B, per_B, nA;
   int accumulate;
   size_t slab_stride;
+  bf16_t* img;  // nullable: bf16 image of dW (same indexing), written together with every FINAL value of dW
 };
 SLAM_DEVICE void bal_tile_rc(int t, int tiles_r, int tiles_c, int group_rows, int& tr_, int& tc_) {
   const int GR = group_rows > 0 ? group_rows : 1;
@@ -1029,9 +1030,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bal_kernel(BalArgs p) {
     }
   }
   const bool add = direct && p.accumulate;
+  bf16_t* const imgt = (direct && p.img) ? p.img + (dst - p.dW) : nullptr;  // unsplit tile: this store is the final value
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
-    float* row = dst + (size_t)(wm * 64 + fm * 16 + l15) * stride + wn * 64 + g * 4;
+    const size_t ro = (size_t)(wm * 64 + fm * 16 + l15) * stride + wn * 64 + g * 4;
+    float* row = dst + ro;
     float4 old[4];
     if (add) {
 #pragma unroll
@@ -1043,6 +1046,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bal_kernel(BalArgs p) {
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
       if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
       *reinterpret_cast<float4*>(row + fn * 16) = o;
+      if (imgt) *reinterpret_cast<uint2*>(imgt + ro + fn * 16) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
     }
   }
 }
@@ -1071,6 +1075,7 @@ __global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actua
     }
   }
   *reinterpret_cast<float4*>(p.dW + off) = s;
+  if (p.img) *reinterpret_cast<uint2*>(p.img + off) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
 }
 
 
@@ -1263,6 +1268,7 @@ struct Tn224Args {
   int tiles_a, tiles_b, KS;
   int T_A, S_A, per_A, T_B, S_B, per_B, nA;
   int accumulate;
+  bf16_t* img;  // nullable: bf16 image of dW (same indexing), written with every FINAL value of dW
 };
 SLAM_DEVICE void tn224_tile(int t, int tiles_b, int& ta, int& tb) { ta = t / tiles_b; tb = t - ta * tiles_b; }
 
@@ -1275,10 +1281,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
   const int wr = wave & 3, wc = wave >> 2;
   const int l15 = lane & 15, g = lane >> 4;
   // ---- which piece of which tile ----
-  int t, ks0, ks1, z;
+  int t, ks0, ks1, z, pieces;
   size_t slab_idx = 0;
   {
     int b = blockIdx.x;
+    pieces = b < p.nA ? p.S_A : p.S_B;
     if (b < p.nA) {
       z = b / p.T_A;
       const int idx = b - z * p.T_A;
@@ -1443,6 +1450,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
     base = p.slab + slab_idx * (size_t)(256 * 224);
     ld = TR ? 256 : 224;
   }
+  bf16_t* const imgt = (direct && pieces == 1 && p.img) ? p.img + (base - p.dW) : nullptr;  // unsplit tile: final values
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
     float4 old[7];
@@ -1460,6 +1468,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
       if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
       *reinterpret_cast<float4*>(ptr[fn]) = o;
+      if (imgt) *reinterpret_cast<uint2*>(imgt + (ptr[fn] - base)) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
     }
   }
 }
@@ -1485,11 +1494,12 @@ __global__ __launch_bounds__(256) void reduce_224_kernel(Tn224Args p, int SA_act
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   *reinterpret_cast<float4*>(dst) = s;
+  if (p.img) *reinterpret_cast<uint2*>(p.img + (dst - p.dW)) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
-                                     int splits, int accumulate) {
+                                     int splits, int accumulate, bf16_t* __restrict__ img) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
@@ -1498,6 +1508,7 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   *reinterpret_cast<float4*>(out + i) = s;
+  if (img) *reinterpret_cast<uint2*>(img + i) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
 }
 
 // nt_store  (field of GemmTune, kernels.h)
@@ -1781,7 +1792,7 @@ static size_t tn224_workspace_bytes(int Mmax, int N, int K) {
   return (size_t)slabs * 256 * 224 * sizeof(float);
 }
 static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-                        float* ws, int orient, int background, hipStream_t st) {
+                        float* ws, int orient, int background, hipStream_t st, bf16_t* img) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
@@ -1798,6 +1809,7 @@ static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumu
   a.T_A = pl.T_A; a.S_A = pl.S_A; a.per_A = pl.per_A; a.T_B = pl.T_B; a.S_B = pl.S_B; a.per_B = pl.per_B;
   a.nA = pl.T_A * pl.S_A;
   a.accumulate = accumulate;
+  a.img = img;
   const int nblk = a.nA + pl.T_B * pl.S_B;
   const int T = pl.T_A + pl.T_B;
   if (pl.tr) {
@@ -1833,12 +1845,12 @@ size_t gemm_tn_workspace_bytes(int Mmax, int N, int K) {
 
 // dW[N,K] (fp32) (+)= dY[M,N]^T X[M,K]; contraction over M; split-K partials in `ws`.
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
-            int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background) {
+            int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background, bf16_t* img) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
   if (const int orient = tn224_orient(M, N, K, background)) {
     const Plan224 pl = tn224_plan(M, N, K, orient, background ? T().tn224_bg_max_split : T().tn224_max_split);
     if ((size_t)pl.slabs * 256 * 224 * sizeof(float) > ws_bytes) return -3;
-    return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st);
+    return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st, img);
   }
   if (tn_bal_ok(M, N, K)) {
     static bool attr = false;
@@ -1857,6 +1869,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
     a.nA = pl.T_A * pl.SA_act;
     a.accumulate = accumulate;
     a.slab_stride = (size_t)N * K;
+    a.img = img;
     a.wsA = ws;
     a.wsB = ws + (pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0);
     const int nblk = a.nA + pl.T_B * pl.SB_act;
@@ -1874,7 +1887,7 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int e = dma_ok ? launch<true, true, true, true>(a, splits, st) : launch<true, true, true, false>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
-  reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate);
+  reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate, img);
   return (int)hipGetLastError();
 }
 

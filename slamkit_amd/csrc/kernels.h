@@ -49,8 +49,10 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K);
 // background = 1: the launch shares the GPU with other streams (the engine's wgrad side stream): plans for CU-time per
 // flop instead of chip fill (no K-splitting on the 256 x 224 kernel)
 // ws_bytes: capacity of `ws` (from gemm_tn_workspace_bytes(Mmax, N, K) with Mmax >= M): a plan that does not fit returns -3
+// img (nullable): bf16 image of dW with the same indexing - every FINAL value of dW (unsplit tile epilogues, slab reduces) is
+// also stored there rounded to nearest even: the communication image of a bf16 gradient exchange, without a conversion pass
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-            float* ws, size_t ws_bytes, hipStream_t st, int background = 0);
+            float* ws, size_t ws_bytes, hipStream_t st, int background = 0, bf16_t* img = nullptr);
 
 // attention.hip
 // launch-shape choices of the backward kernels (engine-owned, "attn_jq" / "attn_kw" / "attn_nch" options):
@@ -75,7 +77,7 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
 int rmsnorm_bwd_blocks(int M);
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st);
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img = nullptr);
 int colsum_blocks(int M);
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st);
 // csq / snq (nullable): the same tables times qscale - the QUERY heads are rotated with these, so that q is stored
@@ -120,6 +122,6 @@ int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, si
                   double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st);
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
-                       int accumulate, hipStream_t st);
+                       int accumulate, hipStream_t st, bf16_t* img = nullptr);  // img: bf16 image of `out` (same indexing), nullable
 
 }  // namespace slam

@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
         "slam_family_name": (C.c_char_p, [C.c_int32]),
         "slam_pack_grads_bf16": (C.c_int, [vp, i64, i64, vp, vp]),
         "slam_unpack_grads_bf16": (C.c_int, [vp, i64, i64, vp, vp]),
+        "slam_set_grad_image": (C.c_int, [vp, vp]),
         "slam_join": (C.c_int, [vp, vp]),
         "slam_zero_grads": (C.c_int, [vp, vp]),
         "slam_cast_params": (C.c_int, [vp, vp, vp]),
@@ -100,6 +101,7 @@ def load_library(path: Optional[str] = None):
         "slam_op_gemm_nn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "slam_op_gemm_tn_workspace": (sz, [C.c_int, C.c_int, C.c_int]),
         "slam_op_gemm_tn": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "slam_op_gemm_tn_image": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
         "slam_op_rmsnorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
         "slam_op_rmsnorm_bwd_workspace": (sz, [C.c_int, C.c_int]),
         "slam_op_rmsnorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
@@ -336,6 +338,14 @@ class Engine:
         """dst_bf16[0:count] = bf16(grads[offset:offset+count]); dst_bf16: a bf16 device tensor (view) of >= count elements."""
         self._ck(self.lib.slam_pack_grads_bf16(self.h, int(offset), int(count), _ptr(dst_bf16),
                                                stream if stream is not None else current_stream_ptr()))
+
+    def set_grad_image(self, grads_bf16):
+        """The next backward also writes every final gradient value into `grads_bf16` (bf16, n_params elements; None = off)."""
+        if grads_bf16 is not None:
+            import torch
+            assert grads_bf16.dtype == torch.bfloat16 and grads_bf16.numel() == self.n_params and grads_bf16.is_cuda
+        self._keep["grad_image"] = grads_bf16
+        self._ck(self.lib.slam_set_grad_image(self.h, _ptr(grads_bf16)))
 
     def unpack_grads_bf16(self, offset: int, count: int, src_bf16, stream=None):
         self._ck(self.lib.slam_unpack_grads_bf16(self.h, int(offset), int(count), _ptr(src_bf16),

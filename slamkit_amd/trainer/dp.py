@@ -71,8 +71,23 @@ class GradBucketReducer:
         self.time_buckets = False   # bracket every bucket's collective with timing events on the communication stream
         self._bucket_ev, self._last_bucket_ev = [], []
 
+    def arm_image(self):
+        """Before the backward whose buckets will be exchanged (the last micro-batch of a step): with a bf16 exchange and an
+        engine that can do it, backward itself writes the bf16 communication image of the gradients (slam_set_grad_image) and
+        the per-bucket pack pass is skipped for this step."""
+        self._image = False
+        if (self.engine is None or not hasattr(self.engine, "set_grad_image") or self.comm_dtype != torch.bfloat16
+                or not self.flat.is_cuda or (self.world == 1 and not self.force) or os.environ.get("SLAM_DP_NO_IMAGE", "0") == "1"):
+            return
+        if self.stage is None:
+            self.stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
+        self.engine.set_grad_image(self.stage)
+        self._image = True
+
     def _pack(self, offset: int, count: int, st: torch.Tensor):
         """st[0:count] = comm_dtype(grads[offset:offset+count]) on the current stream."""
+        if getattr(self, "_image", False):
+            return  # backward wrote the image of this range already
         if self.engine is not None and self.flat.is_cuda and st.dtype == torch.bfloat16 and not ((offset | count) & 3):
             self.engine.pack_grads_bf16(offset, count, st)
         else:
@@ -162,6 +177,7 @@ class GradBucketReducer:
             for w in self.pending:
                 w.wait()
         self.pending = []
+        self._image = False
         self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
         covered = sorted(self.ranges)
         self.ranges = []
@@ -264,6 +280,7 @@ class ShardedGradReducer(GradBucketReducer):
         self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
         assert self._tail_done or self.top >= self.n, "the replicated tail was never exchanged"
         self.buckets, self.cut_hi, self.active, self._tail_done = [], self.top, False, False
+        self._image = False
         covered = sorted(self.ranges)
         self.ranges = []
         return covered

@@ -103,6 +103,8 @@ class SLAMDPOTrainer(SLAMTrainer):
             coef = torch.cat([g, -g])
             last = i == nm - 1
             dp = last and (self.world > 1 or self.reducer.force)
+            if dp:
+                self.reducer.arm_image()
             self.model.backward_sequence_loss(coef, B2, T, 1.0, bucket_layers=a.ddp_bucket_layers if dp else 0,
                                               bucket_cb=self.reducer.on_bucket if dp else None)
             self._loss_acc += losses.mean().detach() / nm

@@ -111,6 +111,7 @@ class SLAMTrainer:
                             num_items_in_batch=num_items_in_batch, return_logits=False)
         loss = out.loss.detach()
         if last_micro and (self.world > 1 or self.reducer.force):
+            self.reducer.arm_image()  # bf16 exchange: this backward writes the communication image itself (no pack pass)
             model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
         else:
             model.backward(grad_scale)

@@ -73,12 +73,12 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, name, force, comm="", algo="", osd=""):
+def _run(tmp_path, name, force, comm="", algo="", osd="", **extra_env):
     import torch
     out = str(tmp_path / f"{name}.pt")
     env = dict(os.environ, SLAM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), OUT=out,
                SLAM_DP_FORCE="1" if force else "0", COMM=comm, ALGO=algo, OSD=osd, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
     r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return torch.load(out)
@@ -125,3 +125,17 @@ def test_rs_ag_forced_single_rank_rccl_is_bit_identical(tmp_path, osd):
     n = rs["n"]
     assert rs["owned"] and sum(c for _, c in rs["owned"]) == (n // 8192) * 8192  # world 1: the shards are the whole buckets
     assert rs["gather_ms"] >= 0.0
+
+
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_bf16_exchange_image_written_by_backward_equals_the_pack_pass(tmp_path, algo):
+    """bf16 gradient exchange (the default ddp_comm_dtype): the communication image comes out of backward itself
+    (slam_set_grad_image: weight-gradient epilogues, slab reduces and the norm / bias finish kernel store the bf16 rounding
+    of every final value) - the run must leave exactly the parameters of the run that packs each bucket with a conversion
+    pass (SLAM_DP_NO_IMAGE=1), with GA = 2 (the image is written by the accumulating, last micro-batch)."""
+    import torch
+    img = _run(tmp_path, "img", True, comm="bfloat16", algo=algo)
+    pack = _run(tmp_path, "pack", True, comm="bfloat16", algo=algo, SLAM_DP_NO_IMAGE="1")
+    assert torch.equal(img["master"], pack["master"]) and torch.equal(img["params"], pack["params"])
+    plain = _run(tmp_path, "plain", False)
+    assert not torch.equal(img["master"], plain["master"])  # the bf16 rounding of the gradients is really in the path

@@ -203,6 +203,32 @@ def test_gemm_tn_224_phase_scheduled(M, N, K):
         lib().slam_set_option(None, b"gemm_tn224", 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 512, 256), (1600, 512, 256), (8192, 1152, 896), (8192, 896, 896), (8192, 512, 896),   # balanced 128 x 128 plans
+                                   (4096, 1024, 896), (8192, 9728, 896), (8192, 896, 4864), (2048, 768, 672),                # 256 x 224, both orientations
+                                   (333, 72, 40)])                                                                            # generic split-K fallback
+@pytest.mark.parametrize("background", [0, 1])
+def test_gemm_tn_bf16_image_is_the_rounded_result(M, N, K, background):
+    """slam_set_grad_image's mechanism, kernel by kernel: whichever kernel stores the FINAL fp32 value of a dW element (an
+    unsplit tile's epilogue, or the slab reduce of a split tile - every plan occurs across these shapes, in the foreground
+    and in the side stream's "background" planning) also stores its bf16 rounding: the image equals dW.to(bf16) bit for bit,
+    on the storing pass and on an accumulating one."""
+    dY, X = rnd(M, N, seed=8), rnd(M, K, seed=9)
+    a, b = dev_bf16(dY), dev_bf16(X)
+    ws = torch.empty(lib().slam_op_gemm_tn_workspace(M, N, K) // 4 + 16, dtype=torch.float32, device="cuda")
+    dW = torch.full((N, K), 3.0, dtype=torch.float32, device="cuda")
+    try:
+        for tn224 in (1, 2):
+            assert lib().slam_set_option(None, b"gemm_tn224", tn224) == 0
+            for acc in (0, 1):
+                img = torch.full((N, K), 7.0, dtype=torch.bfloat16, device="cuda")
+                assert lib().slam_op_gemm_tn_image(ptr(a), ptr(b), ptr(dW), ptr(img), acc, M, N, K, ptr(ws), background, stream()) == 0
+                sync()
+                assert torch.equal(img, dW.to(torch.bfloat16)), (tn224, acc, float((img.float() - dW).abs().max()))
+        check(f"gemm_tn image run {M}x{N}x{K}", dW, 2 * (dY.t() @ X), 1e-5, 1e-4)
+    finally:
+        lib().slam_set_option(None, b"gemm_tn224", 1)
+
+
 # --------------------------------------------------------------------------------------- RMSNorm
 @pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536), (70, 512), (4099, 2048), (8192, 896), (9001, 1536), (16384, 1536)])
 def test_rmsnorm_fwd_bwd(M, H):
