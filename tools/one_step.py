@@ -15,7 +15,8 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 if wl == "slam358m":
     model = UnitLM(UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=bench.V, max_tokens=bench.B * bench.T), seed=0)
-    tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=bench.B, learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0))
+    tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=bench.B, learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0,
+                                                          optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16")))
     n = float(bench.B * bench.T)
     for i in range(3):
         tr.optimizer_step([bench.synth_batch(0, i, dev)], 1e-3, counts=(n, n))
