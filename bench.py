@@ -7,7 +7,7 @@
 
 A "step" = one full optimizer step of configs[1] (Slam-358M, unit_hubert_25 vocab 502, ctx 1024, bf16,
 per-GPU micro-batch 8, GA 1): forward + shifted CE + backward + (N>1: bucketed RCCL gradient all-reduce
-overlapped with backward) + global-norm clip 0.5 + AdamW, on synthetic unit-token batches already
+overlapped with backward) + global-norm clip 0.5 + AdamW (bf16 parameters and moments: the recipe's precision), on synthetic unit-token batches already
 resident in HBM. Weak scaling (per-GPU work fixed). Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
@@ -15,9 +15,13 @@ Extra objects on the line:
                  launch / mean launch time measured here with HIP events on the launch stream, against the
                  2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md). `step_frac` is the whole-step
                  figure: tokens/s x 2.282 GFLOP/token / peak.
+                 `roofline.in_step` - every launch family of the step as it runs IN the step (HIP timing events around each
+                 launch on its own stream, slam_family_ms), dominant family by time named; `roofline.kernels` - the same
+                 families as stand-alone launches.
   hbm_kernels  - the memory-bound kernels (RMSNorm forward / backward, AdamW, gradient norm) timed here: algorithmic bytes /
-                 time against the 8 TB/s HBM peak; `extras` - GA = 16 and the recipe's bf16 optimizer state, measured after
-                 the timed region; config.ms_per_step_median - median of the per-step HIP-event times.
+                 time against the 8 TB/s HBM peak; `extras` - GA = 16, the host boundary, and the fp32-master optimizer (the
+                 headline runs the recipe's own bf16 optimizer state), measured after the timed region;
+                 config.ms_per_step_median - median of the per-step HIP-event times.
   cpu_baseline - the fp32 CPU oracle (oracle/slam_oracle.py, a port of the reference step: it cannot run the
                  reference's cli/train.py itself) timed on this box's host cores on a bounded
                  sample (B=1, T=1024 fwd+bwd+clip+AdamW, median of 3 steps after a warm-up: 10-15 s of CPU work).
@@ -110,19 +114,20 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
             # L2-miss-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
-            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r3_pmc_step.md, row
-            # `gemm_nt_256_kernel<true> [256 blocks] fwd`: 231.9 MB read + 240.1 MB written), not collected live - counters
+            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r4_pmc_step.md, row
+            # `gemm_nt_256_kernel<true> [256 blocks] fwd`: 229.1 MB read + 240.2 MB written), not collected live - counters
             # need rocprofv3 around the process. The write side is exactly algorithmic (159.4 MB gate|up + 79.7 MB act);
-            # the read side is 7.2x the 32 MB of operands: each of the 8 XCD-private L2s streams the 17.4 MB weight.
-            "traffic": 472.0e6, "traffic_source": "recorded: profiles/r3_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/one_step.py, the same persistent launch)",
+            # the read side is 7.1x the 32 MB of operands: each of the 8 XCD-private L2s streams the 17.4 MB weight (L2 misses,
+            # served by the 256 MB infinity cache after the first XCD: FETCH_SIZE is not HBM reads).
+            "traffic": 469.3e6, "traffic_source": "recorded: profiles/r4_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/one_step.py, the same persistent launch)",
             "algorithmic_bytes": 271.2e6}
 
 
 def kernel_rooflines(model, iters=30, warm=10):
-    """The step's launch families by time (profiles/r3_step_kernel_stats.md), each timed live here as a STANDALONE launch
+    """The step's launch families by time (profiles/r4_step_breakdown.md), each timed live here as a STANDALONE launch
     at the bench shape with HIP events on its launch stream: algorithmic flops / mean launch time against the dense bf16
     MFMA peak. (Inside the step the weight-gradient GEMMs run as background launches beside the dgrad chain and every
-    launch takes longer than alone; the in-step durations are in the rocprof summary.)"""
+    launch takes longer than alone; the in-step durations are `roofline.in_step`, measured live, and the rocprof summary.)"""
     from slamkit_amd import engine as E
     lib = E.load_library()
     st = E.current_stream_ptr()
@@ -417,7 +422,8 @@ def bench_qwen1p5b(a, world, rank, dev):
     cfg = UnitLMConfig(base_model_name=W4["name"], vocab_size=W4["vocab"], max_tokens=W4["tokens"])
     model = UnitLM(cfg, seed=0)
     args = SLAMTrainingArguments(per_device_train_batch_size=1, gradient_accumulation_steps=1, learning_rate=5e-4,
-                                 max_grad_norm=0.5, logging_steps=0)
+                                 max_grad_norm=0.5, logging_steps=0,
+                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16"))
     trainer = SLAMTrainer(model=model, args=args)
     nb = 4
     made = [synth_packed_batch(rank, i, dev) for i in range(nb)]
@@ -453,7 +459,7 @@ def bench_qwen1p5b(a, world, rank, dev):
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[3]-shaped: 28 L, H 1536, 12/2 heads of 128, I 8960, vocab 152167, 16384 packed "
-                                   "tokens per micro-batch, random-init weights; full optimizer step",
+                                   "tokens per micro-batch, random-init weights; full optimizer step (AdamW " + args.optim_state_dtype + " state)",
                        "parallelism": f"dp{world}", "final_loss": round(float(trainer._loss_acc) / max(1, trainer._loss_n), 4)},
             "roofline": {"bound": "mfma", "step_tflops_per_gpu": round(flops / dt / 1e12, 1),
                          "step_frac": round(flops / dt / PEAK_BF16, 4), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s"},
@@ -481,7 +487,8 @@ def bench_dpo(a, world, rank, dev):
     def ids(lo, hi):
         return torch.randint(2, V, (int(torch.randint(lo, hi + 1, (1,), generator=g)),), generator=g).tolist()
     pairs = [[{"prompt": ids(25, 75), "chosen": ids(50, 150), "rejected": ids(50, 150)} for _ in range(8)] for _ in range(4)]
-    args = DPOConfig(per_device_train_batch_size=8, learning_rate=5e-5, max_grad_norm=0.5, logging_steps=0, beta=0.1)
+    args = DPOConfig(per_device_train_batch_size=8, learning_rate=5e-5, max_grad_norm=0.5, logging_steps=0, beta=0.1,
+                     optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16"))
     tr = SLAMDPOTrainer(model=model, ref_model=ref, args=args, train_dataset=[r for b in pairs for r in b], processing_class=_Tok())
     batches = [tr._collate_pairs(tr.train_dataset[8 * i: 8 * i + 8]) for i in range(4)]
     toks = [int((b["labels"] != -100).sum()) for b in batches]
@@ -508,7 +515,7 @@ def bench_dpo(a, world, rank, dev):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[4]: DPO on Slam-358M, 8 pairs / GPU / step (16 sequences padded to a multiple of 64 tokens), policy "
-                                   "fwd+bwd + reference fwd, beta 0.1; full optimizer step", "parallelism": f"dp{world}",
+                                   "fwd+bwd + reference fwd, beta 0.1; full optimizer step (AdamW " + args.optim_state_dtype + " state)", "parallelism": f"dp{world}",
                        "completion_tokens_per_s": round(world * done / dt, 1), "tokens_per_batch": [int(b["input_ids"].numel()) for b in batches],
                        "final_loss": round(float(tr._loss_acc) / max(1, tr._loss_n), 4)}}), flush=True)
     if dist.is_initialized():
@@ -630,7 +637,7 @@ def main():
     # The dominant kernel where it runs: three more optimizer steps with timing events around every gate|up projection
     # launch (slam_gateup_launch_ms) - 72 launches between their real neighbours, the launches rocprofv3 reports for the step.
     # (A stand-alone loop of the same launch reads 137-162 us from run to run: 50 back-to-back launches of the
-    # hottest kernel move with the power state of the part, profiles/r3_experiments/README.md.)
+    # hottest kernel move with the power state of the part, profiles/r3_experiments/README.md, profiles/r4_vendor_gemm.md.)
     model.engine.set_option("time_gateup", 1)
     model.engine.set_option("time_param_waits", 1)  # rs_ag: the stall of the forward behind the parameter all-gather
     dp_on = world > 1 or trainer.reducer.force  # SLAM_DP_FORCE=1: the collective path on a 1-rank group (tools/dp1_bench.sh)

@@ -92,7 +92,7 @@ ns = len(steps)
 mean = lambda v: sum(v) / len(v)
 with open(dst, "w") as f:
     f.write(f"# {title}\n\n")
-    f.write(f"Source: `{src}` (rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2`); the {ns} optimizer steps of the timed region (the 3 instrumented steps and the probes that follow are left out).\n\n")
+    f.write(f"Source: `{src}` (rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2`); the {ns} optimizer steps of the timed region (the {skip_last} instrumented steps and the probes that follow are left out).\n\n")
     f.write(f"Step wall time (first kernel start → AdamW end): **{mean(walls)/1e6:.2f} ms** = forward {mean(fw)/1e6:.2f} + backward {mean(bw)/1e6:.2f} + optimizer {mean(op)/1e6:.2f} ms"
             " (rocprofv3 serialises nothing but adds ≈2-3 % to the un-profiled step).\n\n")
     f.write("| stream (HSA queue) | busy ms / step (union of its launch intervals) |\n|---|---|\n")
