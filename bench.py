@@ -217,7 +217,28 @@ def in_step_table(fam):
             r["frac_of_peak_in_step"] = round(flops[name] / (us * 1e-6) / PEAK_BF16, 4)
         rows.append(r)
     rows.sort(key=lambda r: -r["ms_per_step"])
-    return {"dominant_by_time": rows[0]["family"] if rows else None, "families": rows,
+    # by KERNEL (one kernel serves several families): launch time per step and the flops those launches carry
+    kernel_of = {"wd_wgrad": "gemm_tn_224_kernel (256x224 8-phase weight gradient)", "wgu_wgrad": "gemm_tn_224_kernel (256x224 8-phase weight gradient)",
+                 "gateup_fwd": "gemm_nt_256_kernel (256x256 8-phase, persistent)", "down_dgrad_dswiglu": "gemm_nt_256_kernel (256x256 8-phase, persistent)",
+                 "gateup_dgrad": "gemm_nt_224_kernel (256x224 8-phase)", "attn_bwd": "attn_bwd_dq / dkv / reduce kernels", "attn_fwd": "attn_fwd_kernel",
+                 "wo_wgrad": "gemm_tn_bal_kernel + reduce (128x128 balanced weight gradient)", "wqkv_wgrad": "gemm_tn_bal_kernel + reduce (128x128 balanced weight gradient)",
+                 "head_wgrad": "gemm_tn_bal_kernel + reduce (128x128 balanced weight gradient)", "embed_wgrad": "gemm_tn_bal_kernel + reduce (128x128 balanced weight gradient)"}
+    by_kernel = {}
+    for r in rows:
+        k = kernel_of.get(r["family"], "gemm_kernel (128x128, fused epilogues)" if "gflop" in r else "memory-bound kernels (norms, loss)")
+        e = by_kernel.setdefault(k, {"kernel": k, "ms_per_step": 0.0, "gflop_per_step": 0.0})
+        e["ms_per_step"] += r["ms_per_step"]
+        e["gflop_per_step"] += r.get("gflop", 0.0) * r["launches_per_step"]
+    kernels = sorted(by_kernel.values(), key=lambda e: -e["ms_per_step"])
+    for e in kernels:
+        e["ms_per_step"] = round(e["ms_per_step"], 3)
+        e["gflop_per_step"] = round(e["gflop_per_step"], 1)
+        if e["gflop_per_step"]:
+            e["frac_of_peak_in_step"] = round(e["gflop_per_step"] * 1e9 / (e["ms_per_step"] * 1e-3) / PEAK_BF16, 4)
+    return {"dominant_by_time": rows[0]["family"] if rows else None,
+            # the kernel with the most launch time per step and what it achieves THERE (queueing behind the other stream's
+            # blocks included - on the side stream that is most of the difference to the stand-alone figure)
+            "largest_kernel_by_time": kernels[0] if kernels else None, "kernels_by_time": kernels, "families": rows,
             "measured": "HIP timing-event pairs around every launch on its own stream (slam_family_ms), 3 optimizer steps after the timed region"}
 
 

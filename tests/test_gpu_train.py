@@ -165,8 +165,9 @@ def test_loss_curve_200_steps_vs_oracle(state_dtype):
     # tests/test_oracle_golden.py). The worst single step over 200 steps of a rounding-sensitive trajectory is an extreme-value
     # statistic: the engine may sit 2.5 x as far from the oracle / the reference as those three sit from each other over the
     # first 60 steps (floor 1.5 %), 2 x over all 200 (floor 2 %); the smoothed curve (EMA 0.2) 1.25 x (floor 1.5 %).
-    # Measured (round 4, MI355X): bf16 state 1.8 % / 4.7 % / 1.7 % against envelopes of 1.0 % / 4.5 % / 2.1 %; fp32 state
-    # 1.3 % / 5.0 % against 1.2 % / 6.4 %.
+    # Measured (round 4, MI355X): bf16 state 1.4 % / 4.9 % / 2.2 % against envelopes of 1.0 % / 4.5 % / 2.1 %; fp32 state
+    # 1.2 % / 6.1 % / 1.9 % against 1.2 % / 6.4 % / 2.8 % (a change of summation order in any kernel moves these by a few
+    # tenths of a per cent: another realisation of the same process).
     fx = TS.load_fixture()
     leg = list(fx["loss_bf16"] if bf else fx["loss_fp32"])
     pairs = ((emu, ref), (emu, leg), (ref, leg))
