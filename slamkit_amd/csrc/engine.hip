@@ -97,17 +97,11 @@ struct SlamEngine {
   bool time_families = false;
   std::vector<hipEvent_t> fam_ev;                 // pool, reused step after step
   std::vector<std::pair<int, size_t>> fam_marks;  // (family id, index of the pair's first event)
-  // "bwd_edge_values" (experiment): main -> side hand-overs as hipStreamWriteValue64 / hipStreamWaitValue64 on one
-  // signal-memory word instead of an event record + wait per edge
-  int edge_values = 0;
-  uint64_t* edge_word = nullptr;
-  uint64_t edge_seq = 0;
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
   ~SlamEngine() {
     if (wside) { (void)hipStreamSynchronize(wside); (void)hipStreamDestroy(wside); }
-    if (edge_word) (void)hipFree(edge_word);
     for (hipEvent_t e : fam_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_w) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
@@ -564,7 +558,6 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     h->time_gateup = value != 0;
     return SLAM_OK;
   }
-  if (!strcmp(key, "bwd_edge_values") && h) { h->edge_values = value != 0; return SLAM_OK; }
   if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
@@ -714,22 +707,8 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   } shared_guard(&h->gemm_tune, two ? 1 : 0);
   hipStream_t ws = two ? h->wside : st;
   int ev_used = 0;
-  if (two && h->edge_values && !h->edge_word) {
-    int ok = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev);
-    if (!ok || hipExtMallocWithFlags((void**)&h->edge_word, 8, hipMallocSignalMemory) != hipSuccess) { h->edge_values = 0; h->edge_word = nullptr; }
-    else CK((int)hipMemsetAsync(h->edge_word, 0, 8, st));
-  }
   auto edge = [&](hipStream_t from, hipStream_t to) -> int {  // `to` continues after everything enqueued on `from` so far
     if (from == to) return 0;
-    if (h->edge_values && h->edge_word && from == st) {  // main -> side only: one monotonic counter, written in stream order
-      const uint64_t v = ++h->edge_seq;
-      hipError_t r = hipStreamWriteValue64(from, h->edge_word, v, 0);
-      if (r != hipSuccess) return (int)r;
-      return (int)hipStreamWaitValue64(to, h->edge_word, v, hipStreamWaitValueGte, ~0ull);
-    }
     if ((size_t)ev_used >= h->ev_w.size()) return SLAM_ESTATE;
     hipEvent_t e = h->ev_w[ev_used++];
     hipError_t r = hipEventRecord(e, from);
