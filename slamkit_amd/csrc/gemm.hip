@@ -50,7 +50,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_glds", &t->glds, 0, 1}, {"gemm_tn_dma", &t->tn_dma, 0, 1}, {"gemm_group_rows", &t->group_rows, 1, 64},
       {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, 1},
       {"gemm_256_persist", &t->g256_persist, 0, 1}, {"gemm_256", &t->g256, 0, 2}, {"gemm_nt224", &t->nt224, 0, 2},
-      {"gemm_nt224_min_k", &t->nt224_min_k, 0, 1 << 30}, {"gemm_nt128x224", &t->nt128x224, 0, 2}, {"gemm_nt128x224_min_k", &t->nt128x224_min_k, 0, 1 << 30}, {"gemm_256_dswiglu", &t->g256_dswiglu, 0, 1},
+      {"gemm_nt224_min_k", &t->nt224_min_k, 0, 1 << 30}, {"gemm_256_dswiglu", &t->g256_dswiglu, 0, 1},
       {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
@@ -1241,181 +1241,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_224_kernel(GemmArgs p) {
   }
 }
 
-// ---- NT GEMM on 128 x 224 tiles, 4 waves, 8-phase schedule (round 4: the N = 896 launches that run ALONE on the chip) ----------
-// C[M][N] = A[M][K] B[N][K]^T (bf16 out, optional residual): the row-halved gemm_nt_224_kernel. M = 8192 x N = 896 is 128 tiles
-// of 256 x 224 - half the CUs, which is right beside the weight-gradient stream and wrong in the forward, where nothing else
-// runs: here it is 256 tiles of 128 x 224, one per CU. The 128 x 128 kernel these launches used keeps ONE K-tile in flight per
-// block and drains it (vmcnt(0) + barrier) every K-step - two blocks per CU retire two K-steps per DMA round trip, which is
-// where its ~1 PFLOP/s ceiling on long contractions comes from; this kernel keeps the counted, never-draining DMA stream of
-// the 256-wide kernels. Four waves as 2 (rows, 64 each) x 2 (columns, 112 each): a wave owns 64 x 112 like in the 256 x 224
-// kernels (28 fragments, 22 fragment reads per 56 MFMAs of a K-tile). Half-tile images [128 rows][64 k] (16-B chunk swizzle):
-//   H0 = A rows {first 32 of each wave row} (64 of the 128 image rows used) | H1 = B rows {first 64 of each wave column}
-//   H2 = B rows {last 48 of each wave column} (96 used) | H3 = A rows {other 32 of each wave row} (64 used)
-// per K-tile and wave: 2 + 4 + 4 + 2 DMA instructions (16 B per lane each); the counted waits follow from that order.
-__global__ __launch_bounds__(256, 1) void gemm_nt_128x224_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HT = 128 * 128;  // half-tile image bytes
-  constexpr int KT = 4 * HT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave & 1, wc = wave >> 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nblk = p.tiles_r * p.tiles_c;
-  int nid;
-  {
-    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
-    int q = nblk >> 3, r = nblk & 7;
-    nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tr_ = nid / p.tiles_c, tc_ = nid - tr_ * p.tiles_c;  // the column tiles of a row panel sit on one XCD
-  const int row0 = tr_ * 128, col0 = tc_ * 224;
-  const int nk = p.Kc / BK;
-  const uint32_t lds0 = lds_addr(smem);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  uint32_t voa[2][2], vob[2][4];  // [which half][chunk of this lane]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int P = i * 256 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
-    if (i < 2) {  // A halves: image rows 0..63 = 32 rows of each of the two wave rows
-      const int ra0 = (r >> 5) * 64 + (r & 31);
-      voa[0][i] = (uint32_t)(((size_t)ra0 * p.lda + c * 8) * sizeof(bf16_t));
-      voa[1][i] = (uint32_t)(((size_t)(ra0 + 32) * p.lda + c * 8) * sizeof(bf16_t));
-    }
-    const int rb0 = (r >> 6) * 112 + (r & 63);
-    const int r1 = r < 96 ? r : 95;  // image rows 96..127 of H2 are unused: they repeat the last row
-    const int rb1 = (r1 / 48) * 112 + 64 + (r1 % 48);
-    vob[0][i] = (uint32_t)(((size_t)rb0 * p.ldb + c * 8) * sizeof(bf16_t));
-    vob[1][i] = (uint32_t)(((size_t)rb1 * p.ldb + c * 8) * sizeof(bf16_t));
-  }
-  const bf16_t* Ab = p.A + (size_t)row0 * p.lda;
-  const bf16_t* Bb = p.B + (size_t)col0 * p.ldb;
-  auto issue_half = [&](int h, int t) {  // h: 0 = H0 (A), 1 = H1 (B), 2 = H2 (B), 3 = H3 (A)
-    const uint32_t dst = lds0 + (uint32_t)((t & 1) * KT + h * HT) + (uint32_t)wv * 1024u;
-    if (h == 0 || h == 3) {
-      const bf16_t* base = Ab + (size_t)t * BK;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) glds16_sv(base, voa[h ? 1 : 0][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 4096)));
-    } else {
-      const bf16_t* base = Bb + (size_t)t * BK;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) glds16_sv(base, vob[h - 1][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 4096)));
-    }
-  };
-  f32x4_t acc[4][7];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int ka = (l15 >> 1) & 7;
-  auto frag = [&](const char* img, int Pb, int kk) -> uint4 {  // 16-row block Pb of a half-tile image, K-half kk
-    return *reinterpret_cast<const uint4*>(img + (Pb * 16 + l15) * 128 + ((((g + 4 * kk) ^ ka ^ Pb) & 7) << 4));
-  };
-  uint4 afr[2][2], bg0[2][4], bg1[2][3];
-  auto read_A = [&](const char* img) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) afr[kk][f] = frag(img, wr * 2 + f, kk);
-  };
-  auto read_B0 = [&](const char* img) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) bg0[kk][f] = frag(img, wc * 4 + f, kk);
-  };
-  auto read_B1 = [&](const char* img) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int f = 0; f < 3; ++f) bg1[kk][f] = frag(img, wc * 3 + f, kk);
-  };
-  auto mma0 = [&](int ah) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[ah * 2 + fm][fn] = mfma16(bg0[kk][fn], afr[kk][fm], acc[ah * 2 + fm][fn]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto mma1 = [&](int ah) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 3; ++fn) acc[ah * 2 + fm][4 + fn] = mfma16(bg1[kk][fn], afr[kk][fm], acc[ah * 2 + fm][4 + fn]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // outstanding DMA instructions allowed after each wait (issue order per K-tile: H0 2, H1 4, H2 4, H3 2):
-  //   phase 1 needs H2(t): H3(t) + H0(t+1) may fly = 4 (last K-tile: H3(t) = 2)
-  //   phase 2 needs H3(t): H0(t+1) + H1(t+1) = 6 (last: 0)
-  //   phase 4 needs H0(t+1), H1(t+1): H2(t+1) + H3(t+1) = 6
-  auto ktile = [&](int t, auto last_tag) {
-    constexpr bool LAST = decltype(last_tag)::value;
-    const char* buf = smem + (t & 1) * KT;
-    if (!LAST) issue_half(0, t + 1);
-    read_A(buf);
-    read_B0(buf + HT);
-    if (LAST) wait_vmcnt<2>(); else wait_vmcnt<4>();
-    raw_barrier();
-    mma0(0);
-    raw_barrier();
-    if (!LAST) issue_half(1, t + 1);
-    read_B1(buf + 2 * HT);
-    if (LAST) wait_vmcnt<0>(); else wait_vmcnt<6>();
-    raw_barrier();
-    mma1(0);
-    raw_barrier();
-    if (!LAST) issue_half(2, t + 1);
-    read_A(buf + 3 * HT);
-    raw_barrier();
-    mma1(1);
-    raw_barrier();
-    if (!LAST) issue_half(3, t + 1);
-    if (!LAST) wait_vmcnt<6>();
-    raw_barrier();
-    mma0(1);
-    raw_barrier();
-  };
-  issue_half(0, 0);
-  issue_half(1, 0);
-  issue_half(2, 0);
-  issue_half(3, 0);
-  wait_vmcnt<6>();  // H0, H1 of the first K-tile
-  raw_barrier();
-  if (wc == 1) raw_barrier();  // second wave column: one barrier behind (its fragment reads fall under the first column's MFMAs)
-  for (int t = 0; t + 1 < nk; ++t) ktile(t, std::false_type{});
-  ktile(nk - 1, std::true_type{});
-  if (wc == 0) raw_barrier();
-
-  // epilogue: lane holds C[m][n .. n+3] per fragment (8-byte stores; optional residual)
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int m = row0 + wr * 64 + fm * 16 + l15;
-    const size_t rowoff = (size_t)m * p.ldc;
-    uint2 rr[7];
-    if (p.resid) {
-#pragma unroll
-      for (int fn = 0; fn < 7; ++fn)
-        rr[fn] = *reinterpret_cast<const uint2*>(p.resid + rowoff + col0 + wc * 112 + fn * 16 + g * 4);
-    }
-#pragma unroll
-    for (int fn = 0; fn < 7; ++fn) {
-      f32x4_t v = acc[fm][fn];
-      if (p.resid) {
-        v[0] += __uint_as_float(rr[fn].x << 16); v[1] += __uint_as_float(rr[fn].x & 0xffff0000u);
-        v[2] += __uint_as_float(rr[fn].y << 16); v[3] += __uint_as_float(rr[fn].y & 0xffff0000u);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + rowoff + col0 + wc * 112 + fn * 16 + g * 4) = o;
-    }
-  }
-}
-
 // ---- wgrad on 256 x 224 tiles, 8 waves, 8-phase schedule ----------------------------------------------------------------
 // The two big weight gradients of a layer (gate|up: [9728][896], down: [896][4864]; contraction over the M = 8192 tokens)
 // hold 88 % of the wgrad flops and ran at ~930 TFLOP/s on the 128 x 128 one-barrier kernel. Every big matrix of the model
@@ -1778,33 +1603,9 @@ static int launch_nt224(GemmArgs a, hipStream_t st) {
   gemm_nt_224_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
-// 128 x 224 four-wave kernel: the N % 224 == 0 launches that run ALONE on the chip (forward, single-stream backward): plain or
-// residual epilogue. nt128x224: 0 = off, 1 = when the tiles fill the CUs at least 0.8 of whole rounds and the launch is not
-// in shared mode, 2 = whenever the shape allows (tests)
-static bool use_nt128x224(const GemmArgs& a) {
-  if (!T().nt128x224 || (a.R % 128) || (a.Cn % 224) || (a.Kc % BK) || a.Kc < 2 * BK) return false;
-  if (a.bias || a.act || a.gu || a.rope_cos) return false;
-  if (T().nt128x224 == 2) return true;
-  if (T().shared || a.Kc < T().nt128x224_min_k) return false;
-  const int tiles = (a.R / 128) * (a.Cn / 224);
-  return tiles >= 200 && (double)tiles / (double)(((tiles + 255) / 256) * 256) >= 0.8;
-}
-static int launch_nt128x224(GemmArgs a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x224_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  a.tiles_r = a.R / 128;
-  a.tiles_c = a.Cn / 224;
-  gemm_nt_128x224_kernel<<<a.tiles_r * a.tiles_c, 256, 8 * 128 * 128, st>>>(a);
-  return (int)hipGetLastError();
-}
 // NT launches whose rows / contraction are whole tiles: 256 x 256 8-phase kernel or the 128 x 128 DMA kernel
 static int launch_nt_dma(const GemmArgs& a, hipStream_t st) {
   if (use_nt224(a)) return launch_nt224(a, st);
-  if (use_nt128x224(a)) return launch_nt128x224(a, st);
   if (use_256(a)) return launch_256(a, st);
   return launch<false, false, false, true, true>(a, 1, st);
 }

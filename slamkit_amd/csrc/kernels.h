@@ -23,7 +23,6 @@ struct GemmTune {
   int g256_stagger = 1200, g256_stagger_dswiglu = 1200;
   int shared = 0;               // the launches of this call share the GPU with the engine's wgrad stream (set inside slam_backward)
   int nt224 = 1, nt224_min_k = 2048;
-  int nt128x224 = 0, nt128x224_min_k = 0;   // 128 x 224 four-wave NT kernel for the N % 224 == 0 launches outside shared mode
   int tn_splits_override = 0, tn_balanced = 1, bal_bg_max_split = 4;
   int tn224 = 1, tn224_min_m = 16384, tn224_max_split = 16, tn224_bg_min_m = 4096, tn224_bg_max_split = 1;
 };

@@ -121,36 +121,6 @@ def test_gemm_nt_224_tile_kernel(M, N, K):
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 224, 128), (384, 896, 64 * 5), (1024, 448, 64 * 19), (8192, 896, 1152), (8192, 896, 4864)])
-def test_gemm_nt_128x224_four_wave_kernel(M, N, K):
-    """The 128 x 224 / 4-wave / 8-phase NT kernel (round 4: the N = 896 launches outside the two-stream backward), forced on:
-    same bits as the 128 x 128 kernel (identical contraction order), with and without the residual epilogue; both against fp32;
-    bit-identical repeats."""
-    X, W, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, N, seed=4)
-    Xd, Wd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(res)
-    outs = {}
-    try:
-        assert lib().slam_set_option(None, b"gemm_nt224", 0) == 0
-        assert lib().slam_set_option(None, b"gemm_256", 0) == 0
-        for mode in (0, 2, 2):
-            assert lib().slam_set_option(None, b"gemm_nt128x224", mode) == 0
-            Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-            Yr = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-            assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Y), None, None, M, N, K, 1, stream()) == 0
-            assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Yr), None, ptr(rd), M, N, K, 1, stream()) == 0
-            sync()
-            outs.setdefault(mode, []).append((Y, Yr))
-    finally:
-        lib().slam_set_option(None, b"gemm_nt224", 1)
-        lib().slam_set_option(None, b"gemm_256", 1)
-        lib().slam_set_option(None, b"gemm_nt128x224", 0)
-    ref = X @ W.t()
-    check(f"gemm_nt_128x224 {M}x{N}x{K}", outs[2][0][0].float(), ref, 4e-3, 2e-2)
-    check(f"gemm_nt_128x224 resid {M}x{N}x{K}", outs[2][0][1].float(), ref + res, 4e-3, 2e-2)
-    assert torch.equal(outs[0][0][0], outs[2][0][0]) and torch.equal(outs[0][0][1], outs[2][0][1])
-    assert torch.equal(outs[2][0][0], outs[2][1][0]) and torch.equal(outs[2][0][1], outs[2][1][1])
-
-
 def test_gemm_nt_operand_beyond_4GB():
     """A row operand of more than 4 GB (the d-logits of the configs[3] micro-batch: [16384][152320] bf16 = 4.99 GB): the
     per-lane 32-bit DMA offsets are relative to the tile, the 64-bit part rides in the wave-uniform base. Regression for a
