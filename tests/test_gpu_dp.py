@@ -139,3 +139,70 @@ def test_bf16_exchange_image_written_by_backward_equals_the_pack_pass(tmp_path, 
     assert torch.equal(img["master"], pack["master"]) and torch.equal(img["params"], pack["params"])
     plain = _run(tmp_path, "plain", False)
     assert not torch.equal(img["master"], plain["master"])  # the bf16 rounding of the gradients is really in the path
+
+
+DPO_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SLAM_ROOT"])
+from oracle import slam_oracle as O
+from slamkit_amd.model import UnitLM, UnitLMConfig
+from slamkit_amd.tokeniser import UnitTokeniser
+from slamkit_amd.trainer import DPOConfig, SLAMDPOTrainer
+
+force = os.environ.get("SLAM_DP_FORCE") == "1"
+torch.cuda.set_device(0)
+if force:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+cfg = O.TINY
+base = dict(num_hidden_layers=3, hidden_size=cfg.hidden, num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads,
+            head_dim=cfg.head_dim, intermediate_size=cfg.intermediate, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+            tie_word_embeddings=True)
+mk = lambda seed: UnitLM(UnitLMConfig(base_model_name="local", base_config=base, vocab_size=cfg.vocab, max_tokens=2048), seed=seed)
+pol, ref = mk(1), mk(2)
+g = torch.Generator().manual_seed(5)
+units = lambda k: "".join(f"<Un{int(u)}>" for u in torch.randint(0, 500, (k,), generator=g))
+rows = [{"prompt": units(int(torch.randint(5, 20, (1,), generator=g))), "chosen": units(int(torch.randint(10, 40, (1,), generator=g))),
+         "rejected": units(int(torch.randint(10, 40, (1,), generator=g)))} for _ in range(12)]
+args = DPOConfig(per_device_train_batch_size=2, gradient_accumulation_steps=2, learning_rate=1e-3, max_grad_norm=0.5, logging_steps=0,
+                 max_steps=3, warmup_steps=0, warmup_ratio=0.0, ddp_bucket_layers=1, output_dir="/tmp/unused", beta=0.1,
+                 ddp_comm_dtype=os.environ.get("COMM") or None, ddp_algo=os.environ.get("ALGO") or "all_reduce",
+                 optim_state_dtype=os.environ.get("OSD") or "float32")
+tr = SLAMDPOTrainer(model=pol, ref_model=ref, args=args, train_dataset=rows, processing_class=UnitTokeniser(None, load_fe=False))
+assert tr.reducer.force == force
+tr.train()
+torch.cuda.synchronize()
+torch.save({"master": (pol.flat_master if pol.flat_master is not None else pol.flat_params).cpu(), "params": pol.flat_params.cpu(),
+            "reducer": type(tr.reducer).__name__, "steps": tr.state.global_step}, os.environ["OUT"])
+if force:
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("osd", ["float32", "bfloat16"])
+def test_dpo_trainer_forced_single_rank_rccl_is_bit_identical(tmp_path, osd):
+    """SLAMDPOTrainer through the data-parallel path on a 1-rank RCCL group (bucket callback from backward_sequence_loss,
+    reducer, and - under rs_ag - the SHARDED clip + AdamW + parameter all-gather it used to skip): with one rank every
+    collective is the identity, so 3 optimizer steps (GA 2) must leave the parameters of the plain DPO run bit for bit, for
+    both exchange algorithms; the bf16 exchange (image written by backward) is close, not identical."""
+    import torch
+
+    def run(name, force, **env):
+        out = str(tmp_path / f"{name}.pt")
+        e = dict(os.environ, SLAM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), OUT=out, OSD=osd,
+                 SLAM_DP_FORCE="1" if force else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **env)
+        r = subprocess.run([sys.executable, "-c", DPO_WORKER], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return torch.load(out)
+
+    plain = run("plain", False)
+    assert plain["steps"] == 3
+    for algo, red in (("rs_ag", "ShardedGradReducer"), ("all_reduce", "GradBucketReducer")):
+        got = run(algo, True, ALGO=algo, COMM="float32")
+        assert got["reducer"] == red
+        assert torch.equal(plain["master"], got["master"]) and torch.equal(plain["params"], got["params"]), algo
+    bf = run("rs_bf16", True, ALGO="rs_ag", COMM="bfloat16")
+    d = (bf["master"].float() - plain["master"].float()).abs().max().item()
+    assert 0 < d < 5e-3, d
