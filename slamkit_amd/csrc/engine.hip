@@ -312,15 +312,13 @@ int ensure_side(SlamEngine* h) {
 }
 int ensure_wside(SlamEngine* h) {
   if (h->wside && h->wside_cus_applied == h->wside_cus) return 0;
-  hipError_t e = hipSuccess;
-  if (h->wside && h->wside_cus_applied != h->wside_cus) {  // the mask changed: replace the stream
+  hipError_t e;
+  if (h->wside) {  // the mask changed: replace the stream
     (void)hipStreamSynchronize(h->wside);
     (void)hipStreamDestroy(h->wside);
     h->wside = nullptr;
   }
-  if (h->wside) {
-    // keep it
-  } else if (h->wside_cus > 0) {
+  if (h->wside_cus > 0) {
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int n = h->wside_cus > 256 ? 256 : h->wside_cus;
     for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
