@@ -252,8 +252,18 @@ class ShardedGradReducer(GradBucketReducer):
             # model smaller than world x chunk (top == 0) or a first range shorter than the tail gets it with a later callback
             self._tail_done = True
             t0 = self.top
-            self._on_side(ready_stream, lambda: dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group),
-                          tag=("all_reduce (replicated tail)", t0, self.n - t0))
+
+            def tail():  # in the precision of the buckets: every gradient crosses the wire the same way under both algorithms
+                if self.comm_dtype is None:
+                    dist.all_reduce(self.flat[t0:], op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    if self.stage is None:
+                        self.stage = torch.empty(self.n, dtype=self.comm_dtype, device=self.flat.device)
+                    st = self.stage[t0:]
+                    self._pack(t0, self.n - t0, st)
+                    dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+                    self._unpack(t0, self.n - t0, st)
+            self._on_side(ready_stream, tail, tag=("all_reduce (replicated tail)", t0, self.n - t0))
         lo = 0 if offset == 0 else min(self.cut_hi, -(-offset // self.align) * self.align)
         if lo < self.cut_hi:
             hi = self.cut_hi
