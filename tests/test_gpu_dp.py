@@ -249,7 +249,7 @@ tr._gather_optimizer_state()
 torch.cuda.synchronize()
 torch.save({"master": (m.flat_master if m.flat_master is not None else m.flat_params).cpu(), "params": m.flat_params.cpu(),
             "exp_avg": tr.exp_avg.cpu(), "owned": list(getattr(tr.reducer, "owned", []) or []), "seen": tr.state.num_input_tokens_seen,
-            "init": init},
+            "init": init, "grad_norm": float(tr.norm_out[0])},
            os.environ["OUT"] + f".{rank}")
 if world > 1:
     dist.barrier()
@@ -308,4 +308,9 @@ def test_two_ranks_on_one_gpu_real_engine_sharded_equals_replicated(tmp_path, os
     print(f"[parity] world 2 on one GPU (real engine, gloo) vs single process GA 2, {osd} state: update rel-L2 {rel:.2e}, "
           f"elements off by > 1e-5: {frac:.2e}")
     assert torch.equal(two["init"], single["init"]) and float(du_one.norm()) > 0
+    # AdamW and the clip are invariant to the gradient's scale: the pre-clip global norm of the last step pins the scale itself
+    gn2, gn1 = two["grad_norm"], single["grad_norm"]
+    print(f"[parity] global gradient norm of step 3: two ranks {gn2:.6f}, single process {gn1:.6f}")
+    assert abs(gn2 - gn1) <= (2e-3 if osd == "float32" else 2e-2) * gn1, (gn2, gn1)
+    assert res[("float32", "all_reduce")]["grad_norm"] == gn2
     assert rel <= (2e-2 if osd == "float32" else 1e-1), rel
