@@ -569,6 +569,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and rank == 0:
         print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
+    # SLAM_BENCH_DEVICE / SLAM_BENCH_BACKEND: plumbing check of the N > 1 path on a one-GPU box (all ranks on one device,
+    # exchange over gloo) - tools/gpu_r4.sh; a measurement run never sets them
+    local = int(os.environ.get("SLAM_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if os.environ.get("SLAM_BENCH_STREAM", "0") == "1" or int(os.environ.get("SLAM_BWD_WGRAD_CUS", "0")) > 0:
@@ -579,13 +582,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # a hung collective must fail the run in minutes, not after RCCL's default 10-minute watchdog per collective
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get("SLAM_NCCL_TIMEOUT_S", "180"))))
+        backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("SLAM_NCCL_TIMEOUT_S", "180"))),
+                                **({"device_id": dev} if backend == "nccl" else {}))
         # per-rank RCCL sanity line (stderr: stdout carries the ONE JSON line): a one-element all-reduce over the group
         t = torch.ones(1, device=dev)
         dist.all_reduce(t)
         torch.cuda.synchronize()
         print(f"[bench] rank {dist.get_rank()}/{dist.get_world_size()} on cuda:{local} "
-              f"({torch.cuda.get_device_name(local)}): RCCL all-reduce of ones = {float(t):.0f}", file=sys.stderr, flush=True)
+              f"({torch.cuda.get_device_name(local)}): {backend} all-reduce of ones = {float(t):.0f}", file=sys.stderr, flush=True)
         assert float(t) == float(dist.get_world_size())
 
     from slamkit_amd.model import UnitLM, UnitLMConfig
