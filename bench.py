@@ -657,6 +657,10 @@ def main():
         t = torch.tensor([exposed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exposed = float(t)
+        # every rank accumulated local_sum / GLOBAL token count: the global token-mean loss is the sum over ranks
+        t = torch.tensor([loss], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        loss = float(t)
 
     # after the timed region, on EVERY rank: the kernel probes touch the optimizer state (identically on all ranks), the
     # extra steps contain the data-parallel collectives
