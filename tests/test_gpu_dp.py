@@ -235,15 +235,16 @@ tr = SLAMTrainer(model=m, args=args)
 init = (m.flat_master if m.flat_master is not None else m.flat_params).float().cpu().clone()
 g = torch.Generator().manual_seed(0)
 batches = []
+per_step = 2 * int(os.environ.get("MB", "1"))   # micro-batches per optimizer step over all ranks (MB per rank at world 2)
 for step in range(3):
-    for j in range(2):   # two micro-batches per optimizer step: one per rank at world 2, both accumulated (GA 2) at world 1
+    for j in range(per_step):
         ids = torch.randint(2, cfg.vocab, (2, 128), generator=g)
         ids[:, 0] = 1
         lab = ids.clone()
         lab[1, 100 - 10 * j:] = -100
         batches.append({"input_ids": ids, "labels": lab})
 for step in range(3):
-    mine = [batches[2 * step + rank]] if world > 1 else batches[2 * step: 2 * step + 2]
+    mine = batches[per_step * step + rank: per_step * (step + 1): world] if world > 1 else batches[per_step * step: per_step * (step + 1)]
     tr.optimizer_step(mine, 1e-3)
 tr._gather_optimizer_state()
 torch.cuda.synchronize()
@@ -297,6 +298,10 @@ def test_two_ranks_on_one_gpu_real_engine_sharded_equals_replicated(tmp_path, os
             assert torch.equal(a[k], b[k]), (comm, k, float((a[k].float() - b[k].float()).abs().max()))
         own = b["owned"]
         assert own and all(c % 8192 == 0 for _, c in own)
+    # two micro-batches per rank (GA 2): the bf16 image is written by an ACCUMULATING backward, the shards are still halves
+    ga = {algo: _run_world(tmp_path, f"ga2_{algo}", 2, COMM="bfloat16", ALGO=algo, OSD=osd, GA="2", MB="2")[0] for algo in ("all_reduce", "rs_ag")}
+    for k in ("master", "params", "exp_avg"):
+        assert torch.equal(ga["all_reduce"][k], ga["rs_ag"][k]), ("GA 2", k)
     (single,) = _run_world(tmp_path, "single", 1, GA="2", OSD=osd)
     two = res[("float32", "rs_ag")]
     assert single["seen"] == two["seen"] > 0
