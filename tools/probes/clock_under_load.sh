@@ -5,12 +5,12 @@ cd "${GRAFT_REPO_ROOT:-.}"; out=${1:-gpurun_out/clock_under_load.txt}
 poll() { for i in $(seq 1 $1); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power" | tr -s ' \t' ' ' | tr '\n' '|'; echo; sleep 0.4; done; }
 {
 echo "== idle =="; poll 3
-echo "== bench.py --steps 400 (Slam-358M step, ~24 ms per step) =="
-python bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/clock_bench.json 2>/dev/null &
-sleep 14; poll 12; wait
+echo "== bench.py --steps 1500 (Slam-358M step, ~24 ms per step: polled from second 12 to second 24 of its ~45 s) =="
+python bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/clock_bench.json 2>/dev/null &
+sleep 12; poll 24; wait
 python -c "import json;d=json.load(open('gpurun_out/clock_bench.json'));print('bench', d['value'], d['ms_per_step'])"
 echo "== 8192^3 GEMM loops (power_probe) =="
 python tools/probes/power_probe.py 2>/dev/null | tail -16 &
-sleep 9; poll 6; wait
+sleep 7; poll 6; wait
 } > $out 2>&1
 cat $out
