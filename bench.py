@@ -242,6 +242,19 @@ def in_step_table(fam):
             "measured": "HIP timing-event pairs around every launch on its own stream (slam_family_ms), 3 optimizer steps after the timed region"}
 
 
+_JSON_FD = None  # duplicate of the process's original stdout (main)
+
+
+def emit(line: dict) -> None:
+    """The ONE JSON line, on the original stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 PEAK_HBM = 8.0e12  # B/s, MI355X_MICROARCH.md (about 6.3e12 reachable by a streaming copy)
 
 
@@ -430,6 +443,8 @@ def spawn_ranks(n: int) -> None:
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
+    if _JSON_FD is not None:  # the launched ranks inherit the real stdout (rank 0 prints the line there)
+        os.dup2(_JSON_FD, 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -474,7 +489,7 @@ def bench_qwen1p5b(a, world, rank, dev):
     if rank == 0:
         toks = sum(counts[(a.warmup + i) % nb] for i in range(a.steps))
         flops = sum(w4_flops_per_batch(made[(a.warmup + i) % nb][1]) for i in range(a.steps))
-        print(json.dumps({
+        emit(({
             "metric": "train tokens/sec (whole node), Qwen2.5-1.5B-shaped interleaved model ctx=2048 packed",
             "value": round(world * toks / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -484,7 +499,7 @@ def bench_qwen1p5b(a, world, rank, dev):
                        "parallelism": f"dp{world}", "final_loss": round(float(trainer._loss_acc) / max(1, trainer._loss_n), 4)},
             "roofline": {"bound": "mfma", "step_tflops_per_gpu": round(flops / dt / 1e12, 1),
                          "step_frac": round(flops / dt / PEAK_BF16, 4), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s"},
-        }), flush=True)
+        }))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -531,14 +546,14 @@ def bench_dpo(a, world, rank, dev):
         dt = float(t)
     if rank == 0:
         done = sum(toks[(a.warmup + i) % 4] for i in range(a.steps))
-        print(json.dumps({
+        emit(({
             "metric": "DPO preference pairs/sec (whole node), Slam-358M", "value": round(world * 8 * a.steps / dt, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[4]: DPO on Slam-358M, 8 pairs / GPU / step (16 sequences padded to a multiple of 64 tokens), policy "
                                    "fwd+bwd + reference fwd, beta 0.1; full optimizer step (AdamW " + args.optim_state_dtype + " state)", "parallelism": f"dp{world}",
                        "completion_tokens_per_s": round(world * done / dt, 1), "tokens_per_batch": [int(b["input_ids"].numel()) for b in batches],
-                       "final_loss": round(float(tr._loss_acc) / max(1, tr._loss_n), 4)}}), flush=True)
+                       "final_loss": round(float(tr._loss_acc) / max(1, tr._loss_n), 4)}}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -560,6 +575,12 @@ def main():
         cpu_baseline_worker(steps=3, seq=1024)
         return
 
+    # stdout carries exactly ONE line - the JSON: everything else this process (or a library under it: gloo announces its
+    # connections on stdout) prints goes to stderr; the line itself is written to the saved descriptor at the end
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one process per GPU, the reference's own launch model:
         # /root/reference cli/train.py:51,61 reads WORLD_SIZE / RANK set by torchrun, README.md:89)
@@ -740,7 +761,7 @@ def main():
             del trainer, model
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
