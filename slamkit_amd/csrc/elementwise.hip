@@ -160,131 +160,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     dw_part[(size_t)blockIdx.x * H + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
 }
 
-// RMSNorm backward, co-resident form (round 4). In backward this kernel runs on the caller's stream while the engine's
-// weight-gradient stream keeps ONE 512-thread GEMM block on most CUs (gemm_tn_224_kernel: 128 KB of the 160 KB LDS and
-// 2 x 224 of the 512 VGPRs per SIMD). The register-pipelined kernel above needs 144 VGPRs (H 896) / ~200 (H 1536) and 16-24 KB
-// of LDS: none of its waves fits beside such a block, so it only ever ran on the CUs the GEMM launch left free (104 of 256
-// beside the 152-block gate|up weight gradient: 11.3 us alone, 25.7 us in the step = 256/104 of it; 16 of 256 beside the
-// 240-block down-projection weight gradient of the 1536-wide model: 45 -> 257 us). This form fits what is left there:
-// <= 64 VGPRs (one more wave per SIMD) and < 5 KB of LDS. A row is spread over WPR waves, one 16-byte chunk per thread, R
-// rows side by side in a block; the next row group is prefetched into registers (packed) while this one is reduced; x / dy
-// stay packed across the row's dot-product exchange and are unpacked twice instead of holding 16 fp32 values; the weight
-// gradient of a thread's 8 columns accumulates over the block's rows in registers and leaves as one slab row per block
-// (fixed row order: the same bits every run).
-template <int WPR, int R, bool RES>
-__global__ __launch_bounds__(WPR * R * 64, 8) void rmsnorm_bwd_lean_kernel(const bf16_t* __restrict__ dy,
-                                                                           const bf16_t* __restrict__ x,
-                                                                           const bf16_t* __restrict__ w,
-                                                                           const float* __restrict__ rstd,
-                                                                           const bf16_t* __restrict__ dres,
-                                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_part,
-                                                                           int M, int H) {
-  __shared__ float red[2][R * WPR];
-  __shared__ float comb[(R > 1 ? (R - 1) : 1) * WPR * 64 * 8];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int slot = wave / WPR, wis = wave % WPR;
-  const int c = wis * 64 + lane;  // 16-byte chunk of the row
-  const bool act = c * 8 < H;
-  float dwa[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dwa[j] = 0.f;
-  const int ngroups = (M + R - 1) / R;
-  const int nb = gridDim.x, b = blockIdx.x;
-  const int n = b < ngroups ? (ngroups - 1 - b) / nb + 1 : 0;  // row groups of this block: b, b + nb, ...
-  const float invH = 1.f / (float)H;
-  uint4 cx = make_uint4(0, 0, 0, 0), cdy = cx;
-  float cr = 0.f;
-  // row bases are wave-uniform: keep them in SGPRs (scalar base + one 32-bit lane offset per load) instead of letting the
-  // loop carry a 64-bit VGPR induction variable per array
-  const uint32_t voff = (uint32_t)c * 16u;
-  auto rowbase = [&](const bf16_t* p, int row) -> const char* {
-    const size_t o = (size_t)row * (size_t)H * sizeof(bf16_t);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)o), hi = __builtin_amdgcn_readfirstlane((uint32_t)(o >> 32));
-    return reinterpret_cast<const char*>(p) + (((size_t)hi << 32) | lo);
-  };
-  auto load = [&](int k, uint4& lx, uint4& ldy, float& lr) {
-    const int row = __builtin_amdgcn_readfirstlane((b + k * nb) * R + slot);
-    if (row < M) {
-      lr = rstd[row];
-      if (act) {
-        lx = *reinterpret_cast<const uint4*>(rowbase(x, row) + voff);
-        ldy = *reinterpret_cast<const uint4*>(rowbase(dy, row) + voff);
-      }
-    }
-  };
-  auto word = [](const uint4& v, int i) -> uint32_t { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; };
-  auto lo16 = [](uint32_t u) -> float { return __uint_as_float(u << 16); };
-  auto hi16 = [](uint32_t u) -> float { return __uint_as_float(u & 0xffff0000u); };
-  if (n > 0) load(0, cx, cdy, cr);
-  for (int k = 0; k < n; ++k) {
-    uint4 nx = make_uint4(0, 0, 0, 0), ndy = nx;
-    float nr = 0.f;
-    if (k + 1 < n) load(k + 1, nx, ndy, nr);
-    const int row = __builtin_amdgcn_readfirstlane((b + k * nb) * R + slot);
-    const bool live = row < M && act;
-    // the residual gradient of THIS row: issued here, consumed after the dot-product exchange (not carried a row ahead: 4 VGPRs)
-    // (the weight chunk likewise: re-read per row from L1 instead of living in 4 VGPRs across the loop - with it resident the
-    //  residual form spills)
-    uint4 cdr = make_uint4(0, 0, 0, 0), wp = cdr;
-    if (live) wp = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + voff);
-    if (RES && live) cdr = *reinterpret_cast<const uint4*>(rowbase(dres, row) + voff);
-    const float r = cr;
-    float dot = 0.f;
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // two elements per 32-bit word: nothing unpacked is kept
-        const uint32_t ux = word(cx, i), ud = word(cdy, i), uw = word(wp, i);
-        const float x0 = lo16(ux) * r, x1 = hi16(ux) * r, d0 = lo16(ud), d1 = hi16(ud);
-        dot += d0 * lo16(uw) * x0;
-        dot += d1 * hi16(uw) * x1;
-        dwa[2 * i] += d0 * x0;
-        dwa[2 * i + 1] += d1 * x1;
-      }
-    }
-    dot = wave_sum(dot);
-    if (WPR > 1) {  // combine the WPR waves of a row in a fixed order (parity slots: one barrier per row group)
-      if (lane == 0) red[k & 1][wave] = dot;
-      __syncthreads();
-      dot = 0.f;
-#pragma unroll
-      for (int i = 0; i < WPR; ++i) dot += red[k & 1][slot * WPR + i];
-    }
-    dot *= invH * r;
-    if (live) {
-      uint4 ov;
-      uint32_t* op = reinterpret_cast<uint32_t*>(&ov);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t ux = word(cx, i), ud = word(cdy, i), uw = word(wp, i);
-        float o0 = r * (lo16(ud) * lo16(uw) - lo16(ux) * dot), o1 = r * (hi16(ud) * hi16(uw) - hi16(ux) * dot);
-        if (RES) { const uint32_t ua = word(cdr, i); o0 += lo16(ua); o1 += hi16(ua); }
-        op[i] = pack_bf16x2(o0, o1);
-      }
-      *reinterpret_cast<uint4*>(const_cast<char*>(rowbase(dx, row)) + voff) = ov;
-    }
-    cx = nx; cdy = ndy; cr = nr;
-  }
-  // one slab row per block: the R row slots are combined in slot order
-  if (R > 1) {
-    if (slot > 0 && act) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) comb[((slot - 1) * WPR * 64 + c) * 8 + j] = dwa[j];
-    }
-    __syncthreads();
-    if (slot == 0 && act) {
-      for (int s2 = 1; s2 < R; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwa[j] += comb[((s2 - 1) * WPR * 64 + c) * 8 + j];
-    }
-  }
-  if (slot == 0 && act) {
-    float4* o = reinterpret_cast<float4*>(dw_part + (size_t)b * H + c * 8);
-    o[0] = make_float4(dwa[0], dwa[1], dwa[2], dwa[3]);
-    o[1] = make_float4(dwa[4], dwa[5], dwa[6], dwa[7]);
-  }
-}
-
 // column sums of a bf16 matrix (bias gradient): part[blockIdx.y][N] fp32. Block = 16 column chunks (8 columns
 // each) x 16 row lanes; a row lane walks rows lane, lane + 16 gridDim.y, ...; the 16 row lanes are combined in
 // LDS in a fixed order. Algorithmic traffic: 2 B/element read.
@@ -1063,44 +938,12 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
   LAUNCH_RET();
 }
 
-// "norm_bwd_lean": 0 = the register-pipelined kernel everywhere, 1 = the co-resident kernel for rows wider than 1024 (three or
-// four waves per row), 2 = everywhere. Slab rows per [M][H] instance: rmsnorm_bwd_blocks (capacity), rmsnorm_bwd_rows (written).
-static int g_norm_bwd_lean = 0, g_norm_bwd_lean_blocks = 2048;
-void norm_bwd_tune(int lean, int blocks) {
-  if (lean >= 0) g_norm_bwd_lean = lean;
-  if (blocks > 0) g_norm_bwd_lean_blocks = blocks > 2048 ? 2048 : blocks;
-}
-static bool norm_bwd_use_lean(int H) { return g_norm_bwd_lean == 2 || (g_norm_bwd_lean == 1 && H > 1024); }
-static int norm_bwd_R(int H) { const int wpr = (H / 8 + 63) / 64; return wpr == 1 ? 4 : wpr == 2 ? 2 : 1; }
-int rmsnorm_bwd_blocks(int M) { const int g = (M + 15) / 16; return g < 1 ? 1 : (g < 2048 ? g : 2048); }
-int rmsnorm_bwd_rows(int M, int H) {
-  if (!norm_bwd_use_lean(H)) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
-  const int R = norm_bwd_R(H), groups = (M + R - 1) / R, cap = rmsnorm_bwd_blocks(M);
-  int nb = groups < g_norm_bwd_lean_blocks ? groups : g_norm_bwd_lean_blocks;
-  nb = nb < cap ? nb : cap;
-  return nb < 1 ? 1 : nb;
-}
+int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
 
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img) {
   if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
-  int nb = rmsnorm_bwd_rows(M, H);
-  if (norm_bwd_use_lean(H)) {
-#define LEAN(WPR_, R_)                                                                                              \
-    do {                                                                                                            \
-      if (dres) rmsnorm_bwd_lean_kernel<WPR_, R_, true><<<nb, WPR_ * R_ * 64, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); \
-      else rmsnorm_bwd_lean_kernel<WPR_, R_, false><<<nb, WPR_ * R_ * 64, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H);     \
-    } while (0)
-    switch ((H / 8 + 63) / 64) {
-      case 1: LEAN(1, 4); break;
-      case 2: LEAN(2, 2); break;
-      case 3: LEAN(3, 1); break;
-      default: LEAN(4, 1); break;
-    }
-#undef LEAN
-    if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0, dw_img);
-    LAUNCH_RET();
-  }
+  int nb = rmsnorm_bwd_blocks(M);
   switch ((H / 8 + 63) / 64) {
     case 1: rmsnorm_bwd_kernel<1><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
     case 2: rmsnorm_bwd_kernel<2><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;

@@ -556,8 +556,6 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
     h->time_gateup = value != 0;
     return SLAM_OK;
   }
-  if (!strcmp(key, "norm_bwd_lean")) { norm_bwd_tune((int)value, 0); return SLAM_OK; }      // process-wide (kernel selection)
-  if (!strcmp(key, "norm_bwd_blocks")) { norm_bwd_tune(-1, (int)value); return SLAM_OK; }
   if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
@@ -769,7 +767,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     if (l == 0 || boundary) {
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
-      const int nbl = rmsnorm_bwd_rows(M, H), nbc = colsum_blocks(M);
+      const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st, img(o.ln1)));
       CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st, img(o.ln2)));
       CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st, img(o.bqkv)));

@@ -75,9 +75,7 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
 
 // elementwise.hip
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
-int rmsnorm_bwd_blocks(int M);          // slab rows to reserve per [M][H] instance (capacity)
-int rmsnorm_bwd_rows(int M, int H);     // slab rows the next rmsnorm_bwd launch of this shape writes
-void norm_bwd_tune(int lean, int blocks);  // "norm_bwd_lean" (0 / 1 / 2; -1 keeps), "norm_bwd_blocks" (grid of the lean kernel; 0 keeps)
+int rmsnorm_bwd_blocks(int M);
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
                 bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img = nullptr);
 int colsum_blocks(int M);

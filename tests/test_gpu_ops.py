@@ -230,19 +230,8 @@ def test_gemm_tn_bf16_image_is_the_rounded_result(M, N, K, background):
 
 
 # --------------------------------------------------------------------------------------- RMSNorm
-@pytest.mark.parametrize("lean", [0, 2])
 @pytest.mark.parametrize("M,H", [(5, 256), (300, 896), (1000, 1536), (70, 512), (4099, 2048), (8192, 896), (9001, 1536), (16384, 1536)])
-def test_rmsnorm_fwd_bwd(M, H, lean):
-    """lean = 0: the register-pipelined one-wave-per-row backward kernel; lean = 2: the co-resident kernel (<= 64 VGPRs, a row
-    spread over 1-4 waves: H 256 / 512 -> 1, 896 -> 2, 1536 -> 3, 2048 -> 4) forced for every width. Same tolerances."""
-    assert lib().slam_set_option(None, b"norm_bwd_lean", lean) == 0
-    try:
-        _rmsnorm_fwd_bwd(M, H)
-    finally:
-        lib().slam_set_option(None, b"norm_bwd_lean", 0)
-
-
-def _rmsnorm_fwd_bwd(M, H):
+def test_rmsnorm_fwd_bwd(M, H):
     x, w, dy, dres = rnd(M, H, seed=1), 1 + 0.1 * rnd(H, seed=2), rnd(M, H, seed=3), rnd(M, H, seed=4)
     w = w.to(torch.bfloat16).float()
     xd, wd = dev_bf16(x), dev_bf16(w)
