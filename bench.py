@@ -591,7 +591,7 @@ def main():
     if world != a.gpus and rank == 0:
         print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
     # SLAM_BENCH_DEVICE / SLAM_BENCH_BACKEND: plumbing check of the N > 1 path on a one-GPU box (all ranks on one device,
-    # exchange over gloo) - tools/gpu_r4.sh; a measurement run never sets them
+    # exchange over gloo) - tools/gpu_run.sh; a measurement run never sets them
     local = int(os.environ.get("SLAM_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

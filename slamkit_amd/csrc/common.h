@@ -61,6 +61,17 @@ SLAM_DEVICE f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
                                                  __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// D[i][j] += sum_k A[i][k] * B[k][j], 32x32x16 bf16 (32 cycles per SIMD: the shape the part reaches its 2.5 PFLOP/s with;
+// half the operand-register reads and half the issue slots per flop of the 16x16x32 form).
+//   a: lane l supplies A[i = l&31][k = 8(l>>5) .. +7]
+//   b: lane l supplies B[k = 8(l>>5) .. +7][j = l&31]
+//   d: lane l holds D[i = (r&3) + 8(r>>2) + 4(l>>5)][j = l&31], r = 0..15
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+SLAM_DEVICE f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // LDS operand-tile layout shared by GEMM and attention: rows of 64 bf16 (128 B), eight
 // 16-byte chunks per row, chunk index XOR-swizzled with key(row) = ((row>>1) ^ (row>>4)) & 7:
 //  * fragment reads (ds_read_b128: 16 consecutive rows of a 16-aligned group, same chunk) see

@@ -48,13 +48,14 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
   auto clamp = [](long x, long lo, long hi) { return (int)(x < lo ? lo : x > hi ? hi : x); };
   struct { const char* k; int* f; long lo, hi; } tab[] = {
       {"gemm_glds", &t->glds, 0, 1}, {"gemm_tn_dma", &t->tn_dma, 0, 1}, {"gemm_group_rows", &t->group_rows, 1, 64},
-      {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, 1},
+      {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, 3},
       {"gemm_256_persist", &t->g256_persist, 0, 1}, {"gemm_256", &t->g256, 0, 2}, {"gemm_nt224", &t->nt224, 0, 2},
       {"gemm_nt224_min_k", &t->nt224_min_k, 0, 1 << 30}, {"gemm_256_dswiglu", &t->g256_dswiglu, 0, 1},
       {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
-      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000}};
+      {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
+      {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -97,6 +98,7 @@ struct GemmArgs {
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 SLAM_DEVICE void st_out(bf16_t* ptr, const uint4& v, int nt) {
   u32x4_t w = {v.x, v.y, v.z, v.w};
+  if (nt & 2) return;  // probe only (tools/probes/epilogue_cost.py): the launch without its output stores
   if (nt) __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(ptr));
   else *reinterpret_cast<u32x4_t*>(ptr) = w;
 }
@@ -207,6 +209,22 @@ SLAM_DEVICE void glds_offsets_perm(int ld, int nrows, int row0, int tid, uint32_
     voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
   }
 }
+// The same idea for the 32x32x16 MFMA (round 5): a 32-row block of the column tile is the MFMA's row index i, and register
+// r = 4q + e of lane half h = lane >> 5 holds i = e + 4h + 8q. LDS row v of the block holds tile column perm32(v) =
+// 16h + 4q + e, so a lane ends up with the SIXTEEN consecutive output columns 16h .. 16h + 15 of one output row per block.
+SLAM_DEVICE int perm32(int v) { return (((v >> 2) & 1) << 4) | ((v >> 3) << 2) | (v & 3); }
+template <int THREADS, int ROWS>
+SLAM_DEVICE void glds_offsets_perm32(int ld, int nrows, int row0, int tid, uint32_t* voff) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / THREADS; ++i) {
+    int P = i * THREADS + tid;
+    int row = P >> 3, cs = P & 7;
+    int c = cs ^ lds_swz_key(row);
+    int gr = row0 + (row & ~31) + perm32(row & 31);
+    gr = (gr < nrows ? gr : nrows - 1) - row0;
+    voff[i] = (uint32_t)(((size_t)gr * ld + c * 8) * sizeof(bf16_t));
+  }
+}
 template <int THREADS, int ROWS>
 SLAM_DEVICE void glds_tile(const bf16_t* Gk /* = G + k0, wave-uniform */, const uint32_t* voff, int wave,
                            uint32_t tile_lds) {
@@ -287,7 +305,7 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
           du[e] = d * gv[e] * sg;
           dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
         }
-        if (mok) {
+        if (mok && !(p.nt_store & 2)) {
           bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
           *reinterpret_cast<uint4*>(gp) = pack_bf16x8(dg);
           *reinterpret_cast<uint4*>(gp + 32) = pack_bf16x8(du);
@@ -351,10 +369,149 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
   }
 }
 
+// Epilogue of the 32x32x16 kernels: a 64 x 64 piece of the output held as acc[rb][nb] (32-row block rb, 32-column block nb
+// of the perm32 layout): lane (l31, h) holds C[row0 + 32 rb + l31][cbase + 32 nb + 16 h .. +15] in the 16 registers of a
+// block - two 16-byte accesses per block and operand. cbase is a multiple of 64: the 64 columns are one attention head
+// (RoPE: nb = 0 / 1 hold d and d + 32 of the same lane) or one [32 gate | 32 up] block (SwiGLU forward: nb = 0 / 1 are
+// gate and up of the same 16 activation columns). Same fused paths and the same arithmetic per element as epilogue8.
+template <bool LEAN = false>
+SLAM_DEVICE void epilogue32(const GemmArgs& p_, const f32x16_t (&acc)[2][2], int row0, int cbase, int l31, int h) {
+  struct Fields {
+    void* C; bf16_t* act; bf16_t* gu; int R, Cn, ldc, nt_store;
+    const bf16_t* bias; const bf16_t* resid; const float* rope_cos; const float* rope_sin; int rope_heads;
+    const float* rope_cos_q; const float* rope_sin_q; int rope_q_heads;
+  };
+  const Fields p = {p_.C, p_.act, p_.gu, p_.R, p_.Cn, p_.ldc, p_.nt_store,
+                  LEAN ? nullptr : p_.bias, LEAN ? nullptr : p_.resid, LEAN ? nullptr : p_.rope_cos,
+                  LEAN ? nullptr : p_.rope_sin, LEAN ? 0 : p_.rope_heads,
+                  LEAN ? nullptr : p_.rope_cos_q, LEAN ? nullptr : p_.rope_sin_q, LEAN ? 0 : p_.rope_q_heads};
+  const int cl = cbase + 16 * h;  // + 32 nb
+  uint4 bb4[2][2];
+  if (p.bias) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) bb4[nb][u] = *reinterpret_cast<const uint4*>(p.bias + cl + 32 * nb + 8 * u);
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int m = row0 + rb * 32 + l31;
+    const bool mok = m < p.R;
+    const size_t rowoff = (size_t)(mok ? m : 0) * p.ldc;
+    if (p.gu) {
+      // fused SwiGLU backward: acc = d(act)[m][c .. c+15]; gate at gu[m][(c/32)*64 + c%32], up 32 columns later
+      bf16_t* grow = p.gu + (size_t)(mok ? m : 0) * (2 * p.Cn);
+      uint4 gg[2][2], uu[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int c = cl + 32 * nb;
+        const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          gg[nb][u] = *reinterpret_cast<const uint4*>(gp + 8 * u);
+          uu[nb][u] = *reinterpret_cast<const uint4*>(gp + 32 + 8 * u);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int c = cl + 32 * nb;
+        bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float gv[8], uv[8], dg[8], du[8];
+          unpack_bf16x8(gg[nb][u], gv);
+          unpack_bf16x8(uu[nb][u], uv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = acc[rb][nb][8 * u + e];
+            const float sg = fast_sigmoid(gv[e]);
+            du[e] = d * gv[e] * sg;
+            dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+          }
+          if (mok && !(p.nt_store & 2)) {
+            *reinterpret_cast<uint4*>(gp + 8 * u) = pack_bf16x8(dg);
+            *reinterpret_cast<uint4*>(gp + 32 + 8 * u) = pack_bf16x8(du);
+          }
+        }
+      }
+      continue;
+    }
+    uint4 rr4[2][2];
+    if (p.resid) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rr4[nb][u] = *reinterpret_cast<const uint4*>(p.resid + rowoff + cl + 32 * nb + 8 * u);
+    }
+    float v[2][16];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[nb][e] = acc[rb][nb][e];
+      if (p.bias) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float b[8];
+          unpack_bf16x8(bb4[nb][u], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[nb][8 * u + e] += b[e];
+        }
+      }
+      if (p.resid) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float r[8];
+          unpack_bf16x8(rr4[nb][u], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[nb][8 * u + e] += r[e];
+        }
+      }
+    }
+    if (p.rope_cos && mok && (cbase >> 6) < p.rope_heads) {
+      const bool qh = (cbase >> 6) < p.rope_q_heads;  // wave-uniform: the 64 columns are one head
+      const float4* cp = reinterpret_cast<const float4*>((qh ? p.rope_cos_q : p.rope_cos) + (size_t)m * 32 + h * 16);
+      const float4* sp = reinterpret_cast<const float4*>((qh ? p.rope_sin_q : p.rope_sin) + (size_t)m * 32 + h * 16);
+      float cc[16], ss[16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        *reinterpret_cast<float4*>(cc + 4 * u) = cp[u];
+        *reinterpret_cast<float4*>(ss + 4 * u) = sp[u];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float x1 = v[0][e], x2 = v[1][e];
+        v[0][e] = x1 * cc[e] - x2 * ss[e];
+        v[1][e] = x2 * cc[e] + x1 * ss[e];
+      }
+    }
+    if (mok) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          st_out(reinterpret_cast<bf16_t*>(p.C) + rowoff + cl + 32 * nb + 8 * u, pack_bf16x8(v[nb] + 8 * u), p.nt_store);
+      if (p.act) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float a8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gt = acc[rb][0][8 * u + e], up = acc[rb][1][8 * u + e];
+            a8[e] = gt * fast_sigmoid(gt) * up;
+          }
+          st_out(p.act + (size_t)m * (p.Cn / 2) + cbase / 2 + 16 * h + 8 * u, pack_bf16x8(a8), p.nt_store);
+        }
+      }
+    }
+  }
+}
+
 // 4 waves as 2x2 of 64x64, two blocks per CU. GLDS: two-stage LDS-DMA ring (operands whose rows / contraction are whole
 // tiles); otherwise register staging with bounds handling (ragged shapes, NN dgrad without a transposed image).
 // PERM: 8-column epilogue layout (NT DMA form, bf16 output).
-template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false>
+// MF32 (with PERM): the main loop on v_mfma_f32_32x32x16_bf16 - a wave's 64 x 64 are 2 x 2 blocks of 32 x 32, the column
+// tile's rows in the perm32 order, epilogue32.
+template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false, bool MF32 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int THREADS = 256, NSTAGE = 2, BMT = BM;
@@ -362,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   constexpr int NF = 4;   // 16-column fragments per wave
   constexpr int A_BYTES = TILE_BYTES, STAGE = STAGE_BYTES;
   static_assert(!PERM || (GLDS && !(TA && TB) && !F32OUT), "8-column layout: NT DMA kernel, bf16 out");
+  static_assert(!MF32 || PERM, "32x32x16 main loop: NT DMA kernel only");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WNN, wn = wave % WNN;
@@ -394,11 +552,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int kend = min(p.Kc, kbeg + p.kc_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  f32x4_t acc[4][NF];
+  f32x4_t acc[4][NF];     // 16x16x32 form (dead in the MF32 instantiation)
+  f32x16_t acc32[2][2];   // 32x32x16 form: [32-row block][32-column block] (dead otherwise)
+  if constexpr (MF32) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  // 32x32x16 fragments: lane (l31, hh) reads row (w*64 + b*32 + l31), K-step s: chunk (2s + hh) ^ key(row) with
+  // key = ((l31>>1) ^ (l31>>4) ^ (w*4 + b*2)) & 7 (common.h: 16 distinct 16-byte slots per ds_read_b128 lane group)
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int k32 = ((l31 >> 1) ^ (l31 >> 4)) & 7;
+  auto compute32 = [&](int s_) {
+    const char* At = smem + s_ * STAGE;
+    const char* Bt = At + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 af[2], bf[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        af[b] = *reinterpret_cast<const uint4*>(Bt + (wn * 64 + b * 32 + l31) * 128 + ((((2 * ks + hh) ^ k32 ^ (wn * 4 + b * 2)) & 7) << 4));
+        bf[b] = *reinterpret_cast<const uint4*>(At + (wm * 64 + b * 32 + l31) * 128 + ((((2 * ks + hh) ^ k32 ^ (wm * 4 + b * 2)) & 7) << 4));
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc32[rb][nb] = mfma32(af[nb], bf[rb], acc32[rb][nb]);
+    }
+  };
 
   // swizzle key of row (w*64 + f*16 + l15) = ((l15>>1) ^ (w*4 + f)) & 7 = s0 ^ f
   const int s0a = ((l15 >> 1) ^ (wn * NF)) & 7;
@@ -467,7 +656,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       glds_offsets_tr<THREADS, BN>(p.ldb, col0, tid, vob);
     } else {
       glds_offsets<THREADS, BMT>(p.lda, p.R, row0, tid, voa);
-      if constexpr (PERM) glds_offsets_perm<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      if constexpr (MF32) glds_offsets_perm32<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
+      else if constexpr (PERM) glds_offsets_perm<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
       else glds_offsets<THREADS, BN>(p.ldb, p.Cn, col0, tid, vob);
     }
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -489,6 +679,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       __syncthreads();  // everyone's tile-t DMAs landed; everyone is done reading stage (t-1)%NSTAGE
       if (t + D < nk) issue(t + D);
       if constexpr (TR) compute_tr(t % NSTAGE);
+      else if constexpr (MF32) compute32(t % NSTAGE);
       else compute(t % NSTAGE);
     }
   } else {
@@ -534,7 +725,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   // ---- epilogue: lane holds C[m][n..n+3] for each (fm, fn); bias / residual loads are batched
   //      per row so they are all in flight together -------------------------------------------
-  if constexpr (PERM) {
+  if constexpr (MF32) {
+    epilogue32(p, acc32, row0 + wm * 64, col0 + wn * 64, l31, hh);
+    return;
+  } else if constexpr (PERM) {
     epilogue8(p, acc, row0, col0, wm, wn, l15, g);
     return;
   }
@@ -703,7 +897,10 @@ SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // (vmcnt counts stores and loads in one in-order queue: a counted wait after the epilogue would wait for the stores),
 // stores the finished tile and continues with a K-tile whose first two phases need no wait. Dispatch, address set-up and
 // the first-load latency of a tile disappear behind the previous tile's epilogue.
-template <bool PERSIST>
+// MF32 (round 5): the same schedule on v_mfma_f32_32x32x16_bf16 - a phase is 2 (32-row blocks) x 1 (32-column block) x 4
+// K-steps of 16 = 8 MFMAs of 32 cycles instead of 16 of ~17; the same 12 ds_read_b128 per phase (a fragment is now 32 rows
+// x 16 k instead of 16 x 32), the same LDS images; column-tile rows in the perm32 order, epilogue32.
+template <bool PERSIST, bool MF32>
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
@@ -711,6 +908,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
+  const int l31 = lane & 31, hh = lane >> 5;
   const int nblk = p.tiles_r * p.tiles_c;
   int nid, nid_end, nid_step;
   {
@@ -758,17 +956,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int grow = (r >> 6) * 128 + h * 64 + (r & 63);          // relative to the tile origin: 32-bit offsets must not
-        const int gcol = (r >> 5) * 64 + perm64(h * 32 + (r & 31));   // span the matrix (dlogits [16384][152320] is 4.99 GB)
+        const int gcol = (r >> 5) * 64 + (MF32 ? h * 32 + perm32(r & 31) : perm64(h * 32 + (r & 31)));   // span the matrix (dlogits [16384][152320] is 4.99 GB)
         vo[h ? 3 : 0][i] = (uint32_t)(((size_t)grow * p.lda + c * 8) * sizeof(bf16_t));
         vo[1 + h][i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
       }
     }
-    const int l15_ = t_ & 15;
-    ka = (l15_ >> 1) & 7;
+    if constexpr (MF32) {
+      // 32x32x16 fragments: row (wave block + b*32 + l31), K-step s: chunk (2s + hh) ^ key(row), key = ka ^ (row block >> 4)
+      const int l31_ = t_ & 31;
+      ka = ((l31_ >> 1) ^ (l31_ >> 4)) & 7;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) offA[f] = (wr * 64 + f * 16 + l15_) * 128;
+      for (int b = 0; b < 2; ++b) offA[b] = (wr * 64 + b * 32 + l31_) * 128;
+      offB[0] = (wc * 32 + l31_) * 128;
+    } else {
+      const int l15_ = t_ & 15;
+      ka = (l15_ >> 1) & 7;
 #pragma unroll
-    for (int f = 0; f < 2; ++f) offB[f] = (wc * 32 + f * 16 + l15_) * 128;
+      for (int f = 0; f < 4; ++f) offA[f] = (wr * 64 + f * 16 + l15_) * 128;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) offB[f] = (wc * 32 + f * 16 + l15_) * 128;
+    }
   };
   lane_setup(tid);
   // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1); ta / tb: the K-tile's origin in A / B; par: buffer
@@ -779,40 +986,83 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
   };
 
-  f32x4_t acc[2][4][4];
+  f32x4_t acc[2][4][4];      // 16x16x32 form (dead in the MF32 instantiation)
+  f32x16_t acc32[2][2][2];   // 32x32x16 form: [row quadrant mq][32-row block][column quadrant nq]
+  auto zero_acc = [&]() {
+    if constexpr (MF32) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[a][i][j][e] = 0.f;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  zero_acc();
 
-  uint4 afr[2][4], bfr[2][2][2];  // [kk][fm], [nq][kk][fn]
+  uint4 afr[2][4], bfr[2][2][2];  // 16x16x32: [kk][fm], [nq][kk][fn];  32x32x16: A K-step s, block b at afr[s >> 1][2 (s & 1) + b], B at bfr[nq][s >> 1][s & 1]
   auto read_A = [&](const char* half) {
+    if constexpr (MF32) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        afr[kk][f] = *reinterpret_cast<const uint4*>(half + offA[f] + ((((g + 4 * kk) ^ ka ^ (wr * 4 + f)) & 7) << 4));
+        for (int b = 0; b < 2; ++b)
+          afr[ks >> 1][2 * (ks & 1) + b] = *reinterpret_cast<const uint4*>(half + offA[b] + ((((2 * ks + hh) ^ ka ^ (wr * 4 + b * 2)) & 7) << 4));
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          afr[kk][f] = *reinterpret_cast<const uint4*>(half + offA[f] + ((((g + 4 * kk) ^ ka ^ (wr * 4 + f)) & 7) << 4));
+    }
   };
   auto read_B = [&](const char* half, int nq) {
+    if constexpr (MF32) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int ks = 0; ks < 4; ++ks)
+        bfr[nq][ks >> 1][ks & 1] = *reinterpret_cast<const uint4*>(half + offB[0] + ((((2 * ks + hh) ^ ka ^ (wc * 2)) & 7) << 4));
+    } else {
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-        bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(half + offB[f] + ((((g + 4 * kk) ^ ka ^ (wc * 2 + f)) & 7) << 4));
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          bfr[nq][kk][f] = *reinterpret_cast<const uint4*>(half + offB[f] + ((((g + 4 * kk) ^ ka ^ (wc * 2 + f)) & 7) << 4));
+    }
   };
   auto barrier_b = [&]() { raw_barrier(); };
   auto mma = [&](int mq, int nq) {
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (MF32) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int fm = 0; fm < 4; ++fm)
+        for (int b = 0; b < 2; ++b)
+          acc32[mq][b][nq] = mfma32(bfr[nq][ks >> 1][ks & 1], afr[ks >> 1][2 * (ks & 1) + b], acc32[mq][b][nq]);
+    } else {
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn)
-          acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < 2; ++fn)
+            acc[mq][fm][nq * 2 + fn] = mfma16(bfr[nq][kk][fn], afr[kk][fm], acc[mq][fm][nq * 2 + fn]);
+    }
     __builtin_amdgcn_s_setprio(0);
+  };
+  // 64 rows x the wave's 64 columns per call: row quadrant mq of the wave
+  auto store_quadrant = [&](auto lean_tag, int mq, int a_, int b_) {
+    constexpr bool LEAN = decltype(lean_tag)::value;
+    if constexpr (MF32) epilogue32<LEAN>(p, acc32[mq], row0 + wr * 128 + mq * 64, col0 + wc * 64, a_, b_);
+    else epilogue8<LEAN>(p, acc[mq], row0 + wr * 128 + mq * 64, col0, 0, wc, a_, b_);
   };
   // MODE 0: steady state (issues the K-tile at na / nb into the other buffer); 1: last K-tile of the block (nothing to
   // issue, waits drain); 2: first K-tile after a tile boundary of a persistent block - its own half-tiles were drained
@@ -867,8 +1117,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     for (int t = 0; t + 1 < nk; ++t) ktile(t & 1, steady_t{}, ta + (size_t)(t + 1) * BK, tb + (size_t)(t + 1) * BK);
     ktile((nk - 1) & 1, last_t{}, nullptr, nullptr);
     if (wr == 0) raw_barrier();  // balance the barrier count
-    epilogue8(p, acc[0], row0 + wr * 128, col0, 0, wc, l15, g);
-    epilogue8(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15, g);
+    store_quadrant(std::false_type{}, 0, MF32 ? l31 : l15, MF32 ? hh : g);
+    store_quadrant(std::false_type{}, 1, MF32 ? l31 : l15, MF32 ? hh : g);
   } else {
     // one loop body for every tile (no variant diamonds: the accumulators keep their registers): the first K-tile of a
     // tile finds its half-tiles drained, the last one issues the next tile's first K-tile - or, on the block's last tile,
@@ -894,23 +1144,221 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
       par ^= 1;
       if (wr == 0) raw_barrier();  // balance the barrier count: both wave rows leave the tile together
       wait_vmcnt<0>();             // this wave's pieces of the next tile's first K-tile (see MODE 2)
-      int l15e = l15, ge = g;
+      int l15e = MF32 ? l31 : l15, ge = MF32 ? hh : g;
       asm volatile("" : "+v"(l15e), "+v"(ge));  // keeps the epilogue's address arithmetic out of the K loop
-      epilogue8<true>(p, acc[0], row0 + wr * 128, col0, 0, wc, l15e, ge);
-      epilogue8<true>(p, acc[1], row0 + wr * 128 + 64, col0, 0, wc, l15e, ge);
+      store_quadrant(std::true_type{}, 0, l15e, ge);
+      store_quadrant(std::true_type{}, 1, l15e, ge);
       if (!has_next) break;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      zero_acc();
       nid = nnext; row0 = nrow0; col0 = ncol0;
       int t_ = tid;
       asm volatile("" : "+v"(t_));
       lane_setup(t_);
     }
   }
+}
+
+// ---- NT GEMM on 256 x 256 tiles, FOUR waves of 128 x 128 on v_mfma_f32_32x32x16_bf16, persistent blocks (round 5) -------
+// The eight-wave kernel above reads 192 KB of fragments from LDS per 64-deep K-tile (24 KB per wave) and issues 128 MFMAs of
+// the 16x16x32 form per wave. Here a wave owns 128 x 128 of the output - 4 x 4 blocks of 32 x 32, 256 accumulator registers
+// pinned to the AGPR half of the unified file by the MFMA asm's "a" constraint - and a K-tile is four K-steps of 16:
+// 8 ds_read_b128 (4 row-tile + 4 column-tile fragments of 32 rows x 16 k) per 16 MFMAs of 32 cycles: 128 KB of fragment reads
+// per K-tile and 64 MFMA issues per wave instead of 128. One wave per SIMD has no neighbour to hide behind, so the overlap is
+// inside the wave: while the matrix pipe runs K-step s the wave issues the reads of K-step s + 1 into the other fragment
+// register set, and the LDS-DMA of later K-tiles, two instructions per MFMA row of four. Two whole-K-tile LDS buffers
+// (A image | B image, 64 KB each), ONE barrier per K-tile, in front of K-step 3: K-tile t+1 has landed for every wave and
+// every wave has read the last fragments of K-tile t, so K-step 3 reads K-step 0 of tile t+1 and starts the DMA of tile
+// t+2 into the buffer of tile t (first DMA3 pieces; the rest follow in K-step 0 of tile t+1: a piece has 1.5 - 2.5 K-steps
+// to land). Persistent blocks as in the eight-wave kernel: the K-tile sequence runs on across tile boundaries, the
+// accumulators restart through the first K-step's MFMAs (C = 0 inline constant), the epilogue (epilogue32, LEAN) sits
+// between the last K-step of a tile and the first of the next with K-tile 0 of the next tile already in registers / LDS.
+template <int DMA3>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = 256 * 128;   // one operand image: 256 rows x 128 B
+  constexpr int KT = 2 * IMG;      // K-tile buffer: A image | B image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int nblk = p.tiles_r * p.tiles_c;
+  int nid, nid_end, nid_step;
+  {
+    int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    int q = nblk >> 3, r = nblk & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    nid = base + idx;
+    nid_end = base + q + (xcd < r ? 1 : 0);
+    nid_step = (int)(gridDim.x >> 3);
+    if (p.stagger_ticks > 0) {  // blocks with a tile of slack start late: their store bursts fall under the others' K loops
+      const int mine = (nid_end - nid + nid_step - 1) / nid_step, longest = (nid_end - base + nid_step - 1) / nid_step;
+      if (mine < longest) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+    }
+  }
+  if (nid >= nid_end) return;
+  auto tile_origin = [&](int id, int& r0, int& c0) {
+    const int GR = p.group_rows > 0 ? p.group_rows : 1;
+    const int per_group = GR * p.tiles_c;
+    const int grp = id / per_group, in = id - grp * per_group;
+    const int rows_here = min(GR, p.tiles_r - grp * GR);
+    const int tc_ = in / rows_here;
+    r0 = (grp * GR + in - tc_ * rows_here) * 256;
+    c0 = tc_ * 256;
+  };
+  int row0, col0;
+  tile_origin(nid, row0, col0);
+  const int nk = p.Kc / BK;
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t wv1k = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+  // DMA: 8 + 8 pieces of 1 KB per wave per K-tile; LDS chunk P = i * 256 + tid is row P >> 3, slot P & 7 and holds the source
+  // chunk slot ^ key(row). B rows are in the perm32 order of each 32-row block (epilogue32's 16 consecutive columns per lane).
+  uint32_t voa[8], vob[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int P = i * 256 + tid, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
+    const int gcol = (r & ~31) + perm32(r & 31);
+    voa[i] = (uint32_t)(((size_t)r * p.lda + c * 8) * sizeof(bf16_t));      // relative to the tile origin
+    vob[i] = (uint32_t)(((size_t)gcol * p.ldb + c * 8) * sizeof(bf16_t));
+  }
+  // piece q of a K-tile (q < 8: A image, else B image) from the K-tile's origins (ka, kb) into the buffer at `buf`
+  auto issue_piece = [&](int q, const bf16_t* ka_, const bf16_t* kb_, uint32_t buf) __attribute__((always_inline)) {
+    if (q < 8) glds16_m0(ka_, voa[q], buf + wv1k + (uint32_t)(q * 4096));
+    else glds16_m0(kb_, vob[q - 8], buf + (uint32_t)IMG + wv1k + (uint32_t)((q - 8) * 4096));
+  };
+  // fragment (32-row block b of the wave's 128, K-step s): row w*128 + b*32 + l31, chunk (2s + hh) ^ key(row) =
+  // x ^ 2(s ^ b) for the lane constant x = hh ^ ((l31>>1) ^ (l31>>4)) & 7: four lane offsets per operand serve every fragment
+  int lo_a[4], lo_b[4];
+  {
+    const int x = hh ^ (((l31 >> 1) ^ (l31 >> 4)) & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo_a[j] = (wr * 128 + l31) * 128 + (((x ^ (2 * j)) & 7) << 4);
+      lo_b[j] = IMG + (wc * 128 + l31) * 128 + (((x ^ (2 * j)) & 7) << 4);
+    }
+  }
+  f32x16_t acc[2][2][2][2];  // [64-row half][64-column half][32-row block][32-column block]: four epilogue32 pieces
+  u32x4_t fa[2][4], fb[2][4];  // [K-step parity][block]
+  typedef __attribute__((address_space(3))) const u32x4_t* lds_v4_t;
+  auto rd_a = [&](uint32_t buf, int ks, int b) __attribute__((always_inline)) {
+    fa[ks & 1][b] = *(lds_v4_t)(uintptr_t)(buf + (uint32_t)lo_a[(ks ^ b) & 3] + (uint32_t)(b * 4096));
+  };
+  auto rd_b = [&](uint32_t buf, int ks, int b) __attribute__((always_inline)) {
+    fb[ks & 1][b] = *(lds_v4_t)(uintptr_t)(buf + (uint32_t)lo_b[(ks ^ b) & 3] + (uint32_t)(b * 4096));
+  };
+  // the fragments of K-step ks, two per MFMA row: the next K-step's first row needs every B fragment and A block 0
+  auto rd_row = [&](uint32_t buf, int ks, int row) __attribute__((always_inline)) {
+    if (row == 0) { rd_b(buf, ks, 0); rd_b(buf, ks, 1); }
+    else if (row == 1) { rd_b(buf, ks, 2); rd_b(buf, ks, 3); }
+    else if (row == 2) { rd_a(buf, ks, 0); rd_a(buf, ks, 1); }
+    else { rd_a(buf, ks, 2); rd_a(buf, ks, 3); }
+  };
+  auto mma_row = [&](int ks, int rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[rb >> 1][nb >> 1][rb & 1][nb & 1]) : "v"(fb[ks & 1][nb]), "v"(fa[ks & 1][rb]));
+  };
+  auto mma_row_zero = [&](int ks, int rb) __attribute__((always_inline)) {  // C = 0: the accumulators restart
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[rb >> 1][nb >> 1][rb & 1][nb & 1]) : "v"(fb[ks & 1][nb]), "v"(fa[ks & 1][rb]));
+  };
+  // One K-tile. buf holds it, nbuf the next one. (a1, b1): origins of K-tile t+1 (its pieces DMA3..15 are issued in K-step
+  // 0 into nbuf), (a2, b2): origins of K-tile t+2 (pieces 0..DMA3-1 issued in K-step 3 into buf). FIRST: first K-tile of an
+  // output tile (the accumulators restart).
+  auto ktile = [&](uint32_t buf, uint32_t nbuf, const bf16_t* a1, const bf16_t* b1, const bf16_t* a2, const bf16_t* b2,
+                   auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int PER0 = (16 - DMA3 + 3) / 4, PER3 = (DMA3 + 3) / 4;  // pieces per MFMA row
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {  // K-step 0 under the reads of K-step 1
+      rd_row(buf, 1, rb);
+#pragma unroll
+      for (int j = 0; j < PER0; ++j)
+        if (DMA3 + rb * PER0 + j < 16) issue_piece(DMA3 + rb * PER0 + j, a1, b1, nbuf);
+      if constexpr (FIRST) mma_row_zero(0, rb);
+      else mma_row(0, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {  // K-step 1 under the reads of K-step 2
+      rd_row(buf, 2, rb);
+      mma_row(1, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {  // K-step 2 under the reads of K-step 3
+      rd_row(buf, 3, rb);
+      mma_row(2, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // K-tile t+1 has landed (this wave's pieces; the barrier publishes everyone's), every wave has read K-tile t
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {  // K-step 3 under the reads of K-step 0 of the next K-tile
+      rd_row(nbuf, 0, rb);
+#pragma unroll
+      for (int j = 0; j < PER3; ++j)
+        if (rb * PER3 + j < DMA3) issue_piece(rb * PER3 + j, a2, b2, buf);
+      mma_row(3, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // prologue: K-tile 0 of the first tile, whole; then its K-step 0 fragments and the first pieces of K-tile 1
+  const bf16_t* ta = p.A + (size_t)row0 * p.lda;
+  const bf16_t* tb = p.B + (size_t)col0 * p.ldb;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) issue_piece(q, ta, tb, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  raw_barrier();
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) rd_row(lds0, 0, rb);
+#pragma unroll
+  for (int q = 0; q < DMA3; ++q) issue_piece(q, ta + BK, tb + BK, lds0 + (uint32_t)KT);
+  uint32_t par = 0;
+  for (;;) {
+    const int nnext = nid + nid_step;
+    const bool has_next = nnext < nid_end;
+    int nrow0 = row0, ncol0 = col0;
+    if (has_next) tile_origin(nnext, nrow0, ncol0);
+    // the tile the DMA stream runs on into (the block's last tile: this tile once more, never consumed)
+    const bf16_t* na = p.A + (size_t)nrow0 * p.lda;
+    const bf16_t* nb_ = p.B + (size_t)ncol0 * p.ldb;
+    // K-tile 0 (nk >= 2: K-tile 1 is this tile's; K-tile 2 is this tile's or the next tile's first)
+    {
+      const uint32_t buf = lds0 + par * (uint32_t)KT, nbuf = lds0 + (par ^ 1u) * (uint32_t)KT;
+      const bool in2 = 2 < nk;
+      ktile(buf, nbuf, ta + BK, tb + BK, in2 ? ta + 2 * BK : na, in2 ? tb + 2 * BK : nb_, std::true_type{});
+      par ^= 1u;
+    }
+    for (int t = 1; t < nk; ++t) {
+      const uint32_t buf = lds0 + par * (uint32_t)KT, nbuf = lds0 + (par ^ 1u) * (uint32_t)KT;
+      const int u1 = t + 1, u2 = t + 2;
+      const bf16_t* a1 = u1 < nk ? ta + (size_t)u1 * BK : na + (size_t)(u1 - nk) * BK;
+      const bf16_t* b1 = u1 < nk ? tb + (size_t)u1 * BK : nb_ + (size_t)(u1 - nk) * BK;
+      const bf16_t* a2 = u2 < nk ? ta + (size_t)u2 * BK : na + (size_t)(u2 - nk) * BK;
+      const bf16_t* b2 = u2 < nk ? tb + (size_t)u2 * BK : nb_ + (size_t)(u2 - nk) * BK;
+      ktile(buf, nbuf, a1, b1, a2, b2, std::false_type{});
+      par ^= 1u;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the epilogue reads the accumulators
+    {
+      int l31e = l31, he = hh;
+      asm volatile("" : "+v"(l31e), "+v"(he));  // keeps the epilogue's address arithmetic out of the K loop
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          epilogue32<true>(p, acc[a][b], row0 + wr * 128 + a * 64, col0 + wc * 128 + b * 64, l31e, he);
+    }
+    if (!has_next) break;
+    nid = nnext; row0 = nrow0; col0 = ncol0;
+    ta = na; tb = nb_;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-on pieces of the last tile must not land after the block has left
 }
 
 // ---- wgrad with balanced K-splitting ----------------------------------------------------------------
@@ -1514,12 +1962,12 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
 // nt_store  (field of GemmTune, kernels.h)
 // group_rows: step-level A/B on MI355X (same box): 1 -> 32.4 ms, 2 -> 31.2, 3 -> 31.2, 4 -> 31.5, 8 -> 32.8  (field of GemmTune, kernels.h)
 
-template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false>
+template <bool TA, bool TB, bool F32OUT, bool GLDS, bool PERM = false, bool MF32 = false>
 int launch(GemmArgs a, int splits, hipStream_t st) {
   constexpr int lds = 2 * STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, GLDS, PERM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, F32OUT, GLDS, PERM, MF32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -1528,7 +1976,7 @@ int launch(GemmArgs a, int splits, hipStream_t st) {
   a.group_rows = T().group_rows;
   a.nt_store = T().nt_store;
   dim3 grid(a.tiles_r * a.tiles_c, 1, splits);
-  gemm_kernel<TA, TB, F32OUT, GLDS, PERM><<<grid, 256, lds, st>>>(a);
+  gemm_kernel<TA, TB, F32OUT, GLDS, PERM, MF32><<<grid, 256, lds, st>>>(a);
   return (int)hipGetLastError();
 }
 
@@ -1562,8 +2010,10 @@ static bool use_256(const GemmArgs& a) {
 static int launch_256(GemmArgs a, hipStream_t st) {
   static int cus = 0;
   if (!cus) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e != hipSuccess) return (int)e;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
@@ -1576,8 +2026,24 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
   const int tiles = a.tiles_r * a.tiles_c;
-  if (T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos) gemm_nt_256_kernel<true><<<cus, 512, 8 * 128 * 128, st>>>(a);
-  else gemm_nt_256_kernel<false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
+  const bool persist = T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos;
+  if (T().mf32 && T().g256_w4 && persist) {  // four waves of 128 x 128, persistent
+    static bool attr4 = false;
+    if (!attr4) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_w4_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+      if (e != hipSuccess) return (int)e;
+      attr4 = true;
+    }
+    gemm_nt_w4_kernel<8><<<cus, 256, 8 * 128 * 128, st>>>(a);
+    return (int)hipGetLastError();
+  }
+  if (T().mf32) {
+    if (persist) gemm_nt_256_kernel<true, true><<<cus, 512, 8 * 128 * 128, st>>>(a);
+    else gemm_nt_256_kernel<false, true><<<tiles, 512, 8 * 128 * 128, st>>>(a);
+  } else {
+    if (persist) gemm_nt_256_kernel<true, false><<<cus, 512, 8 * 128 * 128, st>>>(a);
+    else gemm_nt_256_kernel<false, false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1603,11 +2069,15 @@ static int launch_nt224(GemmArgs a, hipStream_t st) {
   gemm_nt_224_kernel<<<a.tiles_r * a.tiles_c, 512, 8 * 128 * 128, st>>>(a);
   return (int)hipGetLastError();
 }
+// the 128 x 128 NT DMA kernel on either MFMA shape
+static int launch_nt_128(const GemmArgs& a, hipStream_t st) {
+  return T().mf32 ? launch<false, false, false, true, true, true>(a, 1, st) : launch<false, false, false, true, true>(a, 1, st);
+}
 // NT launches whose rows / contraction are whole tiles: 256 x 256 8-phase kernel or the 128 x 128 DMA kernel
 static int launch_nt_dma(const GemmArgs& a, hipStream_t st) {
   if (use_nt224(a)) return launch_nt224(a, st);
   if (use_256(a)) return launch_256(a, st);
-  return launch<false, false, false, true, true>(a, 1, st);
+  return launch_nt_128(a, st);
 }
 // gemm_tn_dma  (field of GemmTune, kernels.h)
 
@@ -1648,7 +2118,7 @@ int gemm_nt_swiglu(const bf16_t* X, const bf16_t* W, bf16_t* Y, bf16_t* act, int
 int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N, int K, hipStream_t st) {
   if (check_dims(M, N, K, K, K, N) || (K % BK) || (N % BN) || (N % 32)) return -1;
   GemmArgs a{dY, Wt, nullptr, nullptr, nullptr, nullptr, gu, M, N, K, K, K, N, K, (M + BM - 1) / BM, N / BN};
-  if (!T().g256_dswiglu) return launch<false, false, false, true, true>(a, 1, st);
+  if (!T().g256_dswiglu) return launch_nt_128(a, st);
   return launch_nt_dma(a, st);
 }
 

@@ -25,6 +25,13 @@ struct GemmTune {
   int nt224 = 1, nt224_min_k = 2048;
   int tn_splits_override = 0, tn_balanced = 1, bal_bg_max_split = 4;
   int tn224 = 1, tn224_min_m = 16384, tn224_max_split = 16, tn224_bg_min_m = 4096, tn224_bg_max_split = 1;
+  // round 5: main loops on v_mfma_f32_32x32x16_bf16 (1) or on the 16x16x32 form (0) in the kernels that have both
+  // (128 x 128 NT DMA kernel, 256 x 256 kernels); the 32x32 form sums a 64-deep K-tile in four steps of 16, the 16x16 form
+  // in two of 32: results differ in the last bits between the two settings, not between tile shapes under one setting.
+  // Measured and OFF (profiles/r5_power_or_stall.md): the 32x32 form needs 3 % fewer cycles and runs at a 7 % lower clock
+  // under the board's power limit; Slam-358M step 330.7 k (8 waves) / 323.4 k (4 waves) vs 338.8 k tokens/s
+  int mf32 = 0;
+  int g256_w4 = 0;              // 256 x 256 tiles on the persistent four-wave kernel (128 x 128 per wave; needs mf32)
 };
 GemmTune* gemm_default_tune();
 GemmTune* gemm_use_tune(GemmTune* t);  // install t (NULL = process default) for this thread; returns the previous one

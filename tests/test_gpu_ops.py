@@ -14,10 +14,18 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+@pytest.fixture(params=[0, 1], ids=["mfma16x16x32", "mfma32x32x16"])
+def mf32(request):
+    """Main-loop MFMA shape of the kernels that have both (gemm_mf32); the default is restored afterwards."""
+    assert lib().slam_set_option(None, b"gemm_mf32", request.param) == 0
+    yield request.param
+    lib().slam_set_option(None, b"gemm_mf32", 0)
+
+
 @pytest.mark.parametrize("glds", [0, 1])  # register staging / LDS-DMA
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 256, 128), (1000, 1152, 896),
                                    (74, 512, 256)])
-def test_gemm_nt(M, N, K, glds):
+def test_gemm_nt(M, N, K, glds, mf32):
     X, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
     Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)  # keep alive: ptr() borrows
@@ -28,13 +36,14 @@ def test_gemm_nt(M, N, K, glds):
         sync()
         assert rc == 0
         ref = X @ W.t() + (bias if use_bias else 0) + (res if use_res else 0)
-        check(f"gemm_nt {M}x{N}x{K} glds={glds} epi={use_bias}", Y.float(), ref, 4e-3, 2e-2)
+        check(f"gemm_nt {M}x{N}x{K} glds={glds} mf32={mf32} epi={use_bias}", Y.float(), ref, 4e-3, 2e-2)
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 128), (2048, 8192, 192), (4096, 2048, 64 * 5)])
-def test_gemm_nt_256_tile_kernel(M, N, K):
+def test_gemm_nt_256_tile_kernel(M, N, K, mf32):
     """The 256 x 256 / 8-wave / 8-phase kernel (default for the gate|up forward) against the 128 x 128 kernel: same
-    bits for plain, bias + residual and fused-SwiGLU epilogues, and both against the fp32 reference."""
+    bits for plain, bias + residual and fused-SwiGLU epilogues (under either MFMA shape: the contraction order of an output
+    element does not depend on the tile), and both against the fp32 reference."""
     X, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
     Xd, Wd, bd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(bias), dev_bf16(res)
     outs = {}
@@ -59,16 +68,21 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     check("gemm 256 swiglu act", outs[2][3].float(), (F.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(M, N // 2), 6e-3, 3e-2)
 
 
+@pytest.mark.parametrize("variant", [(0, 0), (1, 0), (1, 1)], ids=["mfma16-8wave", "mfma32-8wave", "mfma32-4wave"])
 @pytest.mark.parametrize("M,N,K", [(2304, 8192, 192), (4352, 4096, 64 * 5), (8192, 9728, 896), (4096, 4864, 128)])
-def test_gemm_nt_256_persistent_blocks(M, N, K):
+def test_gemm_nt_256_persistent_blocks(M, N, K, variant):
     """gemm_256_persist: one block per CU walking the tile list, the DMA stream running across tile boundaries - same bits
     as one block per tile (same contraction order per tile) for the plain, fused-SwiGLU-forward and fused-SwiGLU-backward
-    epilogues, on grids with ragged last rounds (288, 272, 1216, 304 tiles); the SwiGLU backward against fp32 as well."""
+    epilogues, on grids with ragged last rounds (288, 272, 1216, 304 tiles); the SwiGLU backward against fp32 as well.
+    Round 5: for the eight-wave kernel on either MFMA shape and for the persistent four-wave kernel (128 x 128 per wave,
+    32x32x16) against the one-block-per-tile eight-wave kernel of the same MFMA shape."""
     X, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     GU = rnd(M, 2 * N, seed=5)
     Xd, Wd, gud = dev_bf16(X), dev_bf16(W), dev_bf16(GU)
     outs = {}
     try:
+        assert lib().slam_set_option(None, b"gemm_mf32", variant[0]) == 0
+        assert lib().slam_set_option(None, b"gemm_256_w4", variant[1]) == 0
         assert lib().slam_set_option(None, b"gemm_256", 2) == 0
         for persist in (0, 1, 1):
             assert lib().slam_set_option(None, b"gemm_256_persist", persist) == 0
@@ -84,6 +98,8 @@ def test_gemm_nt_256_persistent_blocks(M, N, K):
     finally:
         lib().slam_set_option(None, b"gemm_256_persist", 1)
         lib().slam_set_option(None, b"gemm_256", 1)
+        lib().slam_set_option(None, b"gemm_mf32", 0)
+        lib().slam_set_option(None, b"gemm_256_w4", 0)
     for run in outs[1]:
         for a, b in zip(outs[0][0], run):
             assert torch.equal(a, b)
@@ -98,11 +114,13 @@ def test_gemm_nt_256_persistent_blocks(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(256, 224, 128), (512, 896, 64 * 5), (1024, 448, 64 * 19), (8192, 896, 1152)])
 def test_gemm_nt_224_tile_kernel(M, N, K):
     """The 256 x 224 / 8-wave / 8-phase NT kernel (dgrad launches of the two-stream backward), forced on: same bits as the
-    128 x 128 kernel (identical contraction order), with and without the residual epilogue; both against fp32."""
+    128 x 128 kernel on the same MFMA shape (16x16x32: identical contraction order), with and without the residual epilogue;
+    both against fp32."""
     X, W, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, N, seed=4)
     Xd, Wd, rd = dev_bf16(X), dev_bf16(W), dev_bf16(res)
     outs = {}
     try:
+        assert lib().slam_set_option(None, b"gemm_mf32", 0) == 0
         for mode in (0, 2):
             assert lib().slam_set_option(None, b"gemm_nt224", mode) == 0
             assert lib().slam_set_option(None, b"gemm_256", 0) == 0
@@ -115,6 +133,7 @@ def test_gemm_nt_224_tile_kernel(M, N, K):
     finally:
         lib().slam_set_option(None, b"gemm_nt224", 1)
         lib().slam_set_option(None, b"gemm_256", 1)
+        lib().slam_set_option(None, b"gemm_mf32", 0)
     ref = X @ W.t()
     check(f"gemm_nt_224 {M}x{N}x{K}", outs[2][0].float(), ref, 4e-3, 2e-2)
     check(f"gemm_nt_224 resid {M}x{N}x{K}", outs[2][1].float(), ref + res, 4e-3, 2e-2)

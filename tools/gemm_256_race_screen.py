@@ -19,20 +19,26 @@ for it in range(iters):
     g = torch.Generator(device=dev).manual_seed(1000 + it)
     x = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
-    outs = []
-    for mode, persist in ((0, 0), (2, 0), (2, 1)):
-        lib.slam_set_option(None, b"gemm_256", mode if opt == "gemm_256" else 0)
-        lib.slam_set_option(None, b"gemm_256_persist", persist)
-        lib.slam_set_option(None, b"gemm_nt224", mode if opt == "gemm_nt224" else 0)
-        y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-        assert lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 2, st) == 0
-        outs.append(y)
-    torch.cuda.synchronize()
-    for k, o in enumerate(outs[1:]):
-        if not torch.equal(outs[0], o):
-            bad += 1
-            d = (outs[0].float() - o.float()).abs()
-            print(f"MISMATCH nt it={it} {opt} persist={k} shape={M}x{N}x{K} max={float(d.max())} count={int((d > 0).sum())}", flush=True)
+    # (MFMA shape, tile kernel, persistent, four-wave): every output bit for bit against the 128 x 128 kernel on the SAME MFMA shape
+    # (the 256 x 224 kernel has the 16x16x32 main loop only)
+    for mf in ((0, 1) if opt == "gemm_256" else (0,)):
+        lib.slam_set_option(None, b"gemm_mf32", mf)
+        outs = []
+        for mode, persist, w4 in ((0, 0, 0), (2, 0, 0), (2, 1, 0)) + (((2, 1, 1),) if mf else ()):
+            lib.slam_set_option(None, b"gemm_256", mode if opt == "gemm_256" else 0)
+            lib.slam_set_option(None, b"gemm_256_persist", persist)
+            lib.slam_set_option(None, b"gemm_256_w4", w4)
+            lib.slam_set_option(None, b"gemm_nt224", mode if opt == "gemm_nt224" else 0)
+            y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            assert lib.slam_op_gemm_nt(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, M, N, K, 2, st) == 0
+            outs.append(y)
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs[1:]):
+            if not torch.equal(outs[0], o):
+                bad += 1
+                d = (outs[0].float() - o.float()).abs()
+                print(f"MISMATCH nt it={it} {opt} mf32={mf} variant={k} shape={M}x{N}x{K} max={float(d.max())} count={int((d > 0).sum())}", flush=True)
+    lib.slam_set_option(None, b"gemm_mf32", 0); lib.slam_set_option(None, b"gemm_256_w4", 0)
 lib.slam_set_option(None, b"gemm_256", 1); lib.slam_set_option(None, b"gemm_nt224", 1); lib.slam_set_option(None, b"gemm_256_persist", 1)
 tn_shapes = [(8192, 9728, 896), (8192, 896, 4864), (4096, 512, 448), (16384, 1536, 8960), (2048, 1792, 1024)]
 for it in range(iters):

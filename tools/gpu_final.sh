@@ -5,8 +5,8 @@
 tag=${1:-fin}
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$(pwd); O=$R/gpurun_out/${tag}
-[ "${SKIP_FULL:-0}" = 1 ] || bash tools/gpu_r4.sh ${tag} full
-bash tools/gpu_r4.sh ${tag} smoke
+[ "${SKIP_FULL:-0}" = 1 ] || bash tools/gpu_run.sh ${tag} full
+bash tools/gpu_run.sh ${tag} smoke
 (timeout 600 python bench.py 2>${O}_bench_default.err | tail -1) > ${O}_bench_default.json
 python -c "import json;d=json.load(open('${O}_bench_default.json'));print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'])"
 cd /tmp

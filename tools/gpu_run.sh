@@ -1,10 +1,11 @@
 #!/bin/bash
-# One gpurun call of round 4 (replaces the per-session scripts of round 3). Usage on the GPU box, from the repo root:
-#   bash tools/gpu_r4.sh <tag> <stage> [<stage> ...]
+# One gpurun call (rounds 4 and 5). Usage on the GPU box, from the repo root:
+#   bash tools/gpu_run.sh <tag> <stage> [<stage> ...]
 # stages:  t:<pytest -k expression>   targeted GPU tests        full          the whole -m gpu suite
 #          b:<name>[:ENV=V,ENV=V]     bench.py A/B line         smoke         __graft_entry__.smoke()
 #          q:<name>[:ENV=V,...]       bench.py --workload qwen1p5b
-#          p:<script.py>[:args]       a tools/ probe            prof / pmc    kernel trace / counters of bench.py
+#          p:<script.py>[:args]       a tools/probes/ probe     prof / pmc    kernel trace / counters of bench.py
+#          x:<script.py>[:args]       a tools/ script           pos           tools/probes/power_or_stall.py under one PMC pass
 # Every stage runs under its own timeout; results under gpurun_out/<tag>_*.
 tag=$1; shift
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -31,6 +32,12 @@ P
        ;;
     p) scr=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
        (timeout 600 python tools/probes/$scr $(echo $args | tr ',' ' ') 2>&1 | tail -80) > ${O}_probe_$(basename $scr .py).log; tail -3 ${O}_probe_$(basename $scr .py).log;;
+    x) scr=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
+       (timeout ${X_TIMEOUT:-600} python tools/$scr $(echo $args | tr ',' ' ') 2>&1 | tail -${X_TAIL:-80}) > ${O}_x_$(basename $scr .py).log; tail -3 ${O}_x_$(basename $scr .py).log;;
+    pos) R=$(pwd); cd /tmp
+       timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA \
+         --output-format csv -d $R/${O}_pos -o p -- python $R/tools/probes/power_or_stall.py $R/${O}_pos_manifest.json > $R/${O}_pos.log 2>&1
+       cd $R; python tools/probes/power_or_stall_summary.py ${O}_pos ${O}_pos_manifest.json ${O}_pos.md | tail -14;;
     prof) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/${O}_prof -o r4 -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OLDPWD/${O}_prof.log 2>&1; cd $OLDPWD; ls ${O}_prof | head;;
     *) echo "unknown stage $st";;
   esac
