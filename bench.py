@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - train tokens/sec of the Slam-358M pre-training step on N MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus 1 --steps 50 --warmup 10      (the defaults: SURVEY.md §8d protocol)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -376,6 +376,49 @@ def extra_measurements(model, trainer, rank, dev, a):
     return res
 
 
+def dp_variant_table(model, trainer, args, rank, world, dev):
+    """N > 1 only, after the timed region (which stays ddp_algo = rs_ag, bf16 exchange, 4 layers per bucket): the one driver
+    run at N GPUs also decides the open data-parallel questions - 5 optimizer steps (after 2 warm-up steps)
+    of every exchange variant on the same model, max over ranks: ms per step and the exposed communication time of the last
+    step. Every variant is a fresh SLAMTrainer (its own reducer, bucket plan and optimizer state) on the same engine."""
+    import dataclasses
+    from slamkit_amd.trainer import SLAMTrainer
+    variants = [("rs_ag", "bfloat16", 4), ("all_reduce", "bfloat16", 4), ("rs_ag", "float32", 4), ("rs_ag", "bfloat16", 2), ("rs_ag", "bfloat16", 8),
+                ("all_reduce", "bfloat16", 8)]
+    rows = []
+    n_items = float(B * T)
+    batch = [synth_batch(rank, 200, dev)]
+    for algo, cd, bl in variants:
+        model.engine.join()
+        torch.cuda.synchronize()
+        trainer.exp_avg = trainer.exp_avg_sq = None  # one optimizer state at a time
+        a2 = dataclasses.replace(args, ddp_algo=algo, ddp_comm_dtype=cd, ddp_bucket_layers=bl, gradient_accumulation_steps=1)
+        tr = SLAMTrainer(model=model, args=a2)
+        nv = int(os.environ.get("SLAM_BENCH_DP_VARIANT_STEPS", "5"))
+        for _ in range(min(2, nv)):
+            tr.optimizer_step(batch, 1e-3, counts=(n_items, n_items))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nv):
+            tr.optimizer_step(batch, 1e-3, counts=(n_items, n_items))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nv * 1e3
+        ex = tr.reducer.exposed_ms()
+        if world > 1:
+            t = torch.tensor([dt, ex], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, ex = float(t[0]), float(t[1])
+        tr._gather_optimizer_state()
+        rows.append({"algo": algo, "comm_dtype": cd, "bucket_layers": bl, "ms_per_step": round(dt, 3), "exposed_comm_ms": round(ex, 3),
+                     "tokens_per_s": round(world * B * T / (dt * 1e-3), 1)})
+        trainer = tr
+    return rows
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container
     that reports 256 CPUs but is quota-limited to 8 must not spin 256 OpenMP threads)."""
@@ -562,8 +605,8 @@ def bench_dpo(a, world, rank, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY.md §8d protocol: discard >= 10 steps, median of >= 50
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the GA=16 and recipe-optimizer measurements after the timed region")
     ap.add_argument("--grad-accum", type=int, default=1)
@@ -683,6 +726,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         loss = float(t)
 
+    # SURVEY.md §8d protocol (discard >= 10 steps, median of >= 50): whatever K the launcher asked for, 50 more optimizer steps
+    # follow the timed region, each between two HIP events; their median is `config.ms_per_step_median_50` (this rank)
+    n50 = int(os.environ.get("SLAM_BENCH_MEDIAN_STEPS", "50"))  # (the one-GPU gloo plumbing check sets a few: its steps take seconds)
+    marks50 = [torch.cuda.Event(enable_timing=True) for _ in range(n50 + 1)]
+    marks50[0].record()
+    for i in range(n50):
+        step(a.warmup + a.steps + i)
+        marks50[i + 1].record()
+    fence()
+    per50 = sorted(marks50[i].elapsed_time(marks50[i + 1]) for i in range(n50))
+    ms_median_50 = per50[n50 // 2]
+    base_i = a.warmup + a.steps + n50
     # after the timed region, on EVERY rank: the kernel probes touch the optimizer state (identically on all ranks), the
     # extra steps contain the data-parallel collectives
     # The dominant kernel where it runs: three more optimizer steps with timing events around every gate|up projection
@@ -695,7 +750,7 @@ def main():
     trainer.reducer.time_buckets = dp_on
     in_step_ms = []
     for i in range(3):
-        step(a.warmup + a.steps + i)
+        step(base_i + i)
         in_step_ms += model.engine.gateup_launch_ms(24)
     model.engine.set_option("time_gateup", 0)
     # ... and three more with a timing-event pair around EVERY launch family, on the stream each launch goes to
@@ -703,7 +758,7 @@ def main():
     model.engine.set_option("time_families", 1)
     fam = {}
     for i in range(3):
-        step(a.warmup + a.steps + 3 + i)
+        step(base_i + 3 + i)
         for name, ms_ in model.engine.family_ms():
             fam.setdefault(name, []).append(ms_)
     model.engine.set_option("time_families", 0)
@@ -714,6 +769,8 @@ def main():
     hbm = hbm_kernel_rates(model, trainer)
     # the extras are single-GPU context for the headline (GA 16, host boundary, bf16 state); a multi-rank run measures `value` only
     extras = None if (a.no_extras or world > 1) else extra_measurements(model, trainer, rank, dev, a)
+    # N > 1 (or SLAM_DP_FORCE=1 on one rank): the exchange variants, after everything that still uses the headline trainer
+    dp_variants = dp_variant_table(model, trainer, args, rank, world, dev) if dp_on and os.environ.get("SLAM_BENCH_DP_VARIANTS", "1") == "1" else None
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * trained_tokens * a.steps / dt
@@ -722,14 +779,18 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: Slam-358M (Qwen2.5-0.5B body, vocab 502, rope_theta 1e4), ctx=1024, "
-                                   "synthetic unit-token stream, random-init weights; full optimizer step",
+                                   "synthetic unit-token stream, random-init weights; full optimizer step ("
+                                   + ("AdamW on bf16 parameters with bf16 moments" if args.optim_state_dtype == "bfloat16" else "AdamW, state " + args.optim_state_dtype) + ")",
                        "model": "Slam-358M", "global_batch": world * B * a.grad_accum, "micro_batch": B, "seq_len": T,
                        "grad_accum": a.grad_accum, "parallelism": f"dp{world}",
                        "optimizer": ("AdamW fp32 master+moments" if args.optim_state_dtype == "float32" else
                                      "AdamW on bf16 parameters with bf16 moments - the recipe's own precision (reference config/model/slam.yaml:9); "
                                      "fp32-master variant in extras") + ", clip 0.5",
                        "final_loss": round(loss, 4),
+                       "optimizer_state_dtype": args.optim_state_dtype,
                        "ms_per_step_median": round(ms_median, 3), "ms_per_step_min": round(per_step[0], 3),
+                       "ms_per_step_median_50": round(ms_median_50, 3), "median_50_steps": n50,  # 50 further steps after the timed region (median of >= 50)
+                       "tokens_per_s_median_50": round(trained_tokens / (ms_median_50 * 1e-3), 1),  # this rank
                        "tokens_per_s_median_step": round(trained_tokens / (ms_median * 1e-3), 1),  # this rank
                        "ddp_algo": args.ddp_algo if dp_on else None,
                        "exposed_comm_ms_last_step": round(exposed, 3),
@@ -753,10 +814,20 @@ def main():
         roof["step_tflops_per_gpu"] = round(value / world * FLOP_PER_TOKEN / 1e12, 1)
         roof["kernels"] = kernel_rooflines(model)
         roof["in_step"] = in_step_table(fam)
+        # the headline `frac` above is the gate|up projection (the kernel with the most flops and the best fraction); the kernel
+        # with the most LAUNCH TIME per step sits next to it, not three levels down
+        big = roof["in_step"]["largest_kernel_by_time"] or {}
+        roof["dominant_by_time"] = {"kernel": big.get("kernel"), "ms_per_step": big.get("ms_per_step"), "frac": big.get("frac_of_peak_in_step"),
+                                    "what": "sum of in-step launch durations of this kernel (side-stream launches overlap the caller's stream); frac = its flops / that time / peak"}
         out["roofline"] = roof
         out["hbm_kernels"] = hbm
         if extras is not None:
             out["extras"] = extras
+            if "fp32_master_optimizer" in extras:  # like-for-like with rounds 1-3 (fp32 master + fp32 moments), first-class
+                out["value_fp32_master_optimizer"] = extras["fp32_master_optimizer"]["tokens_per_s"]
+        if dp_variants is not None:
+            out.setdefault("extras", {})["dp_variants"] = dp_variants
+            out["extras"]["nccl_env"] = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO", "GPU_MAX_HW_QUEUES")}
         if world == 1 and not a.no_cpu_baseline:
             del trainer, model
             torch.cuda.empty_cache()

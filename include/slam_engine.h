@@ -175,6 +175,9 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* ex
  * After a ranged update the transposed weight images are rebuilt at the start of the next slam_backward. */
 int slam_add_param_wait(SlamEngine* h, int64_t offset, int64_t count, void* event);
 int slam_param_wait_ms(SlamEngine* h, float* total_ms);
+/* Waits since the last call that could NOT be bracketed by timing events (the event pool - 2048 pairs, completed pairs are
+ * folded into the running total and reused - was full of pairs still in flight): 0 means slam_param_wait_ms is complete. */
+int slam_param_wait_untimed(SlamEngine* h, int64_t* n);
 /* Measurement hook of bench.py's `roofline`: with slam_set_option(h, "time_gateup", 1) every forward brackets the gate|up
  * projection launch of each layer (the dominant kernel: fused SwiGLU GEMM, 2 M (2I) H flop) with two timing events on the
  * caller's stream; slam_gateup_launch_ms writes the n_layers durations of the last forward (ms; host-synchronising).

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/slam_engine.h"
@@ -116,6 +117,8 @@ struct SlamEngine {
   std::vector<ParamWait> pwaits;
   std::vector<hipEvent_t> pw_ev;   // timing pairs around the waits (exposed all-gather time), reused step after step
   size_t pw_used = 0;
+  double pw_acc_ms = 0.0;          // waits whose event pairs were folded into a sum when the pool filled up (not yet reported)
+  int64_t pw_untimed = 0;          // waits that could not be bracketed (pool full of pairs still in flight): reported, never silent
   bool params_t_dirty = false;     // ranged optimizer updates leave the transposed weight images stale until backward needs them
   bool time_param_waits = false;   // "time_param_waits": bracket the parameter waits of a forward with timing events (slam_param_wait_ms)
   float* nlse = nullptr;
@@ -356,7 +359,24 @@ int wait_params(SlamEngine* h, int64_t lo, int64_t hi, hipStream_t st) {
     if (w.lo < hi && lo < w.hi) {
       hipError_t r;
       // two timing events per wait are two more packets on the caller's stream: measurement runs only. The pool is read and
-      // reset by slam_param_wait_ms; a caller that never reads it stops being timed after 2048 waits instead of growing it
+      // reset by slam_param_wait_ms. A caller that reads rarely (logging_steps >> 80) fills it: the pairs that have completed
+      // - all but the last step's - are folded into a running sum and their slots reused, so the reported total stays complete;
+      // a wait that still finds no slot is counted in pw_untimed (slam_param_wait_untimed) instead of vanishing
+      if (h->time_param_waits && h->pw_used + 2 > 4096) {
+        size_t keep = 0;
+        for (size_t k = 0; k + 1 < h->pw_used; k += 2) {
+          float ms = 0.f;
+          if (hipEventQuery(h->pw_ev[k + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->pw_ev[k], h->pw_ev[k + 1]) == hipSuccess) {
+            h->pw_acc_ms += ms;
+          } else {  // still in flight: keep the pair (swap it to the front)
+            std::swap(h->pw_ev[keep], h->pw_ev[k]);
+            std::swap(h->pw_ev[keep + 1], h->pw_ev[k + 1]);
+            keep += 2;
+          }
+        }
+        h->pw_used = keep;
+        if (h->pw_used + 2 > 4096) ++h->pw_untimed;
+      }
       if (h->time_param_waits && h->pw_used + 2 <= 4096) {
         if (h->pw_used + 2 > h->pw_ev.size()) {
           for (int k = 0; k < 2; ++k) {
@@ -1038,7 +1058,15 @@ int slam_param_wait_ms(SlamEngine* h, float* total_ms) {
     if (hipEventSynchronize(h->pw_ev[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->pw_ev[i], h->pw_ev[i + 1]) == hipSuccess) tot += ms;
   }
   h->pw_used = 0;
-  *total_ms = tot;
+  *total_ms = tot + (float)h->pw_acc_ms;
+  h->pw_acc_ms = 0.0;
+  return SLAM_OK;
+}
+
+int slam_param_wait_untimed(SlamEngine* h, int64_t* n) {
+  if (!h || !n) return SLAM_EINVAL;
+  *n = h->pw_untimed;
+  h->pw_untimed = 0;
   return SLAM_OK;
 }
 

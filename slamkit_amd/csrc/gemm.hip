@@ -55,7 +55,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
       {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
+      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -93,6 +93,7 @@ struct GemmArgs {
   const float* rope_sin_q;
   int rope_q_heads;
   int stagger_ticks;  // persistent 256 x 256 blocks with one tile fewer than the longest start this many 10-ns ticks late
+  int cohorts;        // > 1: the slots of an XCD in this many contiguous cohorts, cohort c starts c * stagger_ticks late (every block)
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -923,9 +924,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
       // tile) in lockstep. Slots whose tile list is one shorter than the longest have a whole tile period of slack: they
       // start late, so their epilogues fall under the other blocks' K loops at no cost in makespan.
       const int mine = (nid_end - nid + nid_step - 1) / nid_step, longest = (nid_end - base + nid_step - 1) / nid_step;
-      if (mine < longest) {
+      // cohorts > 1 (round 5 probe): EVERY slot is delayed by its cohort's offset - the long tile lists sit in the low
+      // slots, i.e. in the early cohorts
+      const int delay = p.cohorts > 1 ? (idx * p.cohorts / nid_step) * p.stagger_ticks : (mine < longest ? p.stagger_ticks : 0);
+      if (delay > 0) {
         const uint64_t t0 = wall_clock64();
-        while (wall_clock64() - t0 < (uint64_t)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+        while (wall_clock64() - t0 < (uint64_t)delay) __builtin_amdgcn_s_sleep(32);
       }
     }
   }
@@ -2025,6 +2029,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.nt_store = T().nt_store;
   a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
+  a.cohorts = T().g256_cohorts;
   const int tiles = a.tiles_r * a.tiles_c;
   const bool persist = T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos;
   if (T().mf32 && T().g256_w4 && persist) {  // four waves of 128 x 128, persistent

@@ -255,7 +255,17 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
     have_cache = bool(saved) and os.path.isfile(os.path.join(saved, "_COMPLETE"))
     # a directory with shards but no marker was written before the marker existed, or by an interrupted run: the reference
     # treats an existing directory as the cache (hf_dataset.py:31-33) - re-tokenising over it would mix old and new shards
-    legacy = bool(saved) and not have_cache and os.path.isdir(os.path.join(saved, "train")) and bool(os.listdir(os.path.join(saved, "train")))
+    # (every split directory counts: a cache holding only validation/ must not be rebuilt over either)
+    def _has_shards(split):
+        d = os.path.join(saved, split)
+        return os.path.isdir(d) and bool(os.listdir(d))
+    legacy = bool(saved) and not have_cache and any(_has_shards(sp) for sp in ("train", "validation"))
+    # opt-in (data.accept_unmarked_cache or SLAM_ACCEPT_UNMARKED_CACHE=1): load a marker-less directory as the cache, with a
+    # warning - what the reference does with any existing directory, and what caches written before the marker existed need
+    accept = bool(_get(data, "accept_unmarked_cache", False)) or os.environ.get("SLAM_ACCEPT_UNMARKED_CACHE", "0") == "1"
+    if legacy and accept and _has_shards("train"):
+        logger.warning(f"{saved} has token shards but no _COMPLETE marker: loading it as the cache because accept_unmarked_cache is set")
+        have_cache, legacy = True, False
     import torch.distributed as _dist
     _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
     if _multi:
@@ -264,8 +274,8 @@ def init_dataset(cfg, tokeniser) -> Tuple[Dict[str, object], object]:
         have_cache, legacy = bool(flag[0]), bool(flag[1])
     if legacy:
         raise RuntimeError(f"{saved} holds token shards but no _COMPLETE marker: either an earlier version wrote it (verify it, then "
-                           f"`touch {os.path.join(saved, '_COMPLETE')}` to accept it as the cache) or a run was interrupted while "
-                           f"writing it (delete the directory to rebuild)")
+                           f"`touch {os.path.join(saved, '_COMPLETE')}` or set data.accept_unmarked_cache / SLAM_ACCEPT_UNMARKED_CACHE=1 "
+                           f"to accept it as the cache) or a run was interrupted while writing it (delete the directory to rebuild)")
     if saved and have_cache:
         logger.info(f"Loading dataset from {saved}")
         dataset = {s: TokenShardDataset(os.path.join(saved, s)) for s in ("train", "validation")

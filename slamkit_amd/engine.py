@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None):
         "slam_adamw_range_bf16": (C.c_int, [vp, i64, i64, vp, vp, vp, f64, f64, f64, f64, f64, i32, i32, vp]),
         "slam_add_param_wait": (C.c_int, [vp, i64, i64, vp]),
         "slam_param_wait_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "slam_param_wait_untimed": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "slam_gateup_launch_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int32]),
         "slam_family_ms": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
         "slam_family_name": (C.c_char_p, [C.c_int32]),
@@ -319,6 +320,12 @@ class Engine:
         out = C.c_float(0.0)
         self._ck(self.lib.slam_param_wait_ms(self.h, C.byref(out)))
         return float(out.value)
+
+    def param_wait_untimed(self) -> int:
+        """Parameter waits since the last call that the engine could not time (0 = param_wait_ms() was complete)."""
+        out = C.c_int64(0)
+        self._ck(self.lib.slam_param_wait_untimed(self.h, C.byref(out)))
+        return int(out.value)
 
     def gateup_launch_ms(self, n_layers: int):
         """Durations (ms) of the gate|up projection launches of the last forward (option time_gateup = 1)."""

@@ -197,15 +197,25 @@ class SLAMTrainer:
             for micro in groups:
                 yield micro, None
             return
-        prev = None
-        for micro in groups:
-            c = self.local_counts(micro)
-            cur = (micro, (c, self.post_counts(*c)))
-            if prev is not None:
-                yield prev
-            prev = cur
-        if prev is not None:
-            yield prev
+        pending = None  # the step whose count collective is posted and not yet handed out
+        try:
+            for micro in groups:
+                c = self.local_counts(micro)
+                cur = (micro, (c, self.post_counts(*c)))
+                if pending is not None:
+                    ready, pending = pending, cur
+                    yield ready
+                else:
+                    pending = cur
+            if pending is not None:
+                ready, pending = pending, None
+                yield ready
+        finally:
+            # the consumer left early (max_steps, a stopper callback - decided identically on every rank, _sync_control): the
+            # collective posted for the step that will not run is still in flight; drain it before save / evaluate /
+            # destroy_process_group issue their own collectives on the group
+            if pending is not None and pending[1][1][0] is not None:
+                pending[1][1][0].wait()
 
     # ---- one optimizer step over `micro` collated CPU micro-batches -------------------------------------
     def local_counts(self, micro):
@@ -353,6 +363,7 @@ class SLAMTrainer:
         rec = {"step": self.state.global_step, "loss": loss, "grad_norm": float(self.norm_out[0]), "learning_rate": lr,
                "exposed_comm_ms": self.reducer.exposed_ms(),
                "exposed_param_gather_ms": (self.model.engine.param_wait_ms() if hasattr(self.model.engine, "param_wait_ms") else 0.0),
+               "param_waits_untimed": (self.model.engine.param_wait_untimed() if hasattr(self.model.engine, "param_wait_untimed") else 0),
                "num_input_tokens_seen": self.state.num_input_tokens_seen,
                "tokens_per_sec": (self.state.num_input_tokens_seen - tokens0) / max(dt, 1e-9)}
         self.state.log_history.append(rec)
@@ -381,29 +392,35 @@ class SLAMTrainer:
                 break
             batches = self._epoch_batches(epoch)[skip:]
             skip = 0
-            for micro, handle in self._counts_ahead(self._micro_batches(batches, a.gradient_accumulation_steps)):
-                lr = a.learning_rate * lr_lambda(a, self.state.global_step, max_steps)
-                if handle is None:
-                    self.optimizer_step(micro, lr)
-                else:
-                    self.optimizer_step(micro, lr, counts=handle[0], counts_handle=handle[1])
-                self.state.epoch = self.state.global_step / updates_per_epoch
-                for cb in self.callbacks:
-                    cb.on_step_end(a, self.state, self.control)
-                if self.world > 1 and self.callbacks:
-                    self._sync_control()
-                if a.logging_steps and self.state.global_step % a.logging_steps == 0:
-                    self._log(lr, t0, tokens0)
-                if (a.eval_strategy == "steps" and a.eval_steps and self.state.global_step % a.eval_steps == 0) \
-                        or self.control.should_evaluate:
-                    self.evaluate()
-                    self.control.should_evaluate = False
-                if (a.save_steps and self.state.global_step % a.save_steps == 0) or self.control.should_save:
-                    self.save_checkpoint()
-                    self.control.should_save = False
-                if self.state.global_step >= max_steps or self.control.should_training_stop:
-                    done = True
-                    break
+            steps = self._counts_ahead(self._micro_batches(batches, a.gradient_accumulation_steps))
+            try:
+                for micro, handle in steps:
+                    lr = a.learning_rate * lr_lambda(a, self.state.global_step, max_steps)
+                    if handle is None:
+                        self.optimizer_step(micro, lr)
+                    else:
+                        self.optimizer_step(micro, lr, counts=handle[0], counts_handle=handle[1])
+                    self.state.epoch = self.state.global_step / updates_per_epoch
+                    for cb in self.callbacks:
+                        cb.on_step_end(a, self.state, self.control)
+                    if self.world > 1 and self.callbacks:
+                        self._sync_control()
+                    if self.state.global_step >= max_steps or self.control.should_training_stop:
+                        done = True
+                        steps.close()  # drains the count collective posted one step ahead BEFORE the collectives of log / evaluate / save
+                    if a.logging_steps and self.state.global_step % a.logging_steps == 0:
+                        self._log(lr, t0, tokens0)
+                    if (a.eval_strategy == "steps" and a.eval_steps and self.state.global_step % a.eval_steps == 0) \
+                            or self.control.should_evaluate:
+                        self.evaluate()
+                        self.control.should_evaluate = False
+                    if (a.save_steps and self.state.global_step % a.save_steps == 0) or self.control.should_save:
+                        self.save_checkpoint()
+                        self.control.should_save = False
+                    if done:
+                        break
+            finally:
+                steps.close()
         if self._loss_n:
             self._log(a.learning_rate * lr_lambda(a, max(self.state.global_step - 1, 0), max_steps), t0, tokens0)
         # rs_ag: master weights / moments of the shards other ranks own are stale until gathered - bring them up to date so

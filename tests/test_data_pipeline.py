@@ -107,6 +107,18 @@ def test_binary_shard_roundtrip_and_saved_ds_path(golden_data, tmp_path):
     with pytest.raises(RuntimeError, match="_COMPLETE"):
         init_dataset(cfg, _tok())
     assert (saved / "train" / "tokens.bin").read_bytes() == before
+    # ... unless the run opts in (the reference loads any existing directory, hf_dataset.py:30-32): loaded as it is, with a warning
+    cfg.data["accept_unmarked_cache"] = True
+    ds3, _ = init_dataset(cfg, _tok())
+    assert isinstance(ds3["train"], TokenShardDataset) and len(ds3["train"]) == len(ds["train"])
+    assert (saved / "train" / "tokens.bin").read_bytes() == before
+    cfg.data["accept_unmarked_cache"] = False
+    # a marker-less cache that holds only validation/ is not rebuilt over either
+    import shutil
+    os.rename(saved / "train", saved / "validation")
+    with pytest.raises(RuntimeError, match="_COMPLETE"):
+        init_dataset(cfg, _tok())
+    shutil.rmtree(saved)
 
 
 def test_interleave_datasets_matches_hf_datasets_index_stream():

@@ -38,6 +38,14 @@ P
        timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA \
          --output-format csv -d $R/${O}_pos -o p -- python $R/tools/probes/power_or_stall.py $R/${O}_pos_manifest.json > $R/${O}_pos.log 2>&1
        cd $R; python tools/probes/power_or_stall_summary.py ${O}_pos ${O}_pos_manifest.json ${O}_pos.md | tail -14;;
+    pmcx) R=$(pwd); scr=${rest%%:*}; cd /tmp   # pmcx:<tools/probes script writing a manifest>: one PMC pass + the power_or_stall summary
+       timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA \
+         --output-format csv -d $R/${O}_pmcx -o p -- python $R/tools/probes/$scr $R/${O}_pmcx_manifest.json > $R/${O}_pmcx.log 2>&1
+       cd $R; python tools/probes/power_or_stall_summary.py ${O}_pmcx ${O}_pmcx_manifest.json ${O}_pmcx.md | tail -14;;
+    dp2) # plumbing check of bench.py's N > 1 path on the one GPU: two ranks on device 0, exchange over gloo (NOT a measurement)
+       (env SLAM_BENCH_BACKEND=gloo SLAM_BENCH_DEVICE=0 SLAM_BENCH_MEDIAN_STEPS=3 SLAM_BENCH_DP_VARIANT_STEPS=1 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+          --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>${O}_dp2.err | tail -1) > ${O}_dp2.json
+       python -c "import json;d=json.load(open('${O}_dp2.json'));print('dp2', d['n_gpus'], d['value'], d['config'].get('ms_per_step_median_50'), json.dumps(d.get('extras'))[:1500])" || tail -5 ${O}_dp2.err;;
     prof) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/${O}_prof -o r4 -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OLDPWD/${O}_prof.log 2>&1; cd $OLDPWD; ls ${O}_prof | head;;
     *) echo "unknown stage $st";;
   esac
