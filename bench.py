@@ -376,7 +376,7 @@ def extra_measurements(model, trainer, rank, dev, a):
     return res
 
 
-def dp_variant_table(model, trainer, args, rank, world, dev):
+def dp_variant_table(model, trainer, args, rank, world, dev, rows):
     """N > 1 only, after the timed region (which stays ddp_algo = rs_ag, bf16 exchange, 4 layers per bucket): the one driver
     run at N GPUs also decides the open data-parallel questions - 5 optimizer steps (after 2 warm-up steps)
     of every exchange variant on the same model, max over ranks: ms per step and the exposed communication time of the last
@@ -385,7 +385,6 @@ def dp_variant_table(model, trainer, args, rank, world, dev):
     from slamkit_amd.trainer import SLAMTrainer
     variants = [("rs_ag", "bfloat16", 4), ("all_reduce", "bfloat16", 4), ("rs_ag", "float32", 4), ("rs_ag", "bfloat16", 2), ("rs_ag", "bfloat16", 8),
                 ("all_reduce", "bfloat16", 8)]
-    rows = []
     n_items = float(B * T)
     batch = [synth_batch(rank, 200, dev)]
     for algo, cd, bl in variants:
@@ -416,7 +415,6 @@ def dp_variant_table(model, trainer, args, rank, world, dev):
         rows.append({"algo": algo, "comm_dtype": cd, "bucket_layers": bl, "ms_per_step": round(dt, 3), "exposed_comm_ms": round(ex, 3),
                      "tokens_per_s": round(world * B * T / (dt * 1e-3), 1)})
         trainer = tr
-    return rows
 
 
 def usable_cores() -> int:
@@ -769,8 +767,7 @@ def main():
     hbm = hbm_kernel_rates(model, trainer)
     # the extras are single-GPU context for the headline (GA 16, host boundary, bf16 state); a multi-rank run measures `value` only
     extras = None if (a.no_extras or world > 1) else extra_measurements(model, trainer, rank, dev, a)
-    # N > 1 (or SLAM_DP_FORCE=1 on one rank): the exchange variants, after everything that still uses the headline trainer
-    dp_variants = dp_variant_table(model, trainer, args, rank, world, dev) if dp_on and os.environ.get("SLAM_BENCH_DP_VARIANTS", "1") == "1" else None
+    out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * trained_tokens * a.steps / dt
@@ -825,9 +822,30 @@ def main():
             out["extras"] = extras
             if "fp32_master_optimizer" in extras:  # like-for-like with rounds 1-3 (fp32 master + fp32 moments), first-class
                 out["value_fp32_master_optimizer"] = extras["fp32_master_optimizer"]["tokens_per_s"]
-        if dp_variants is not None:
-            out.setdefault("extras", {})["dp_variants"] = dp_variants
+    # N > 1 (or SLAM_DP_FORCE=1 on one rank): the exchange variants, LAST - the line above is complete without them. A variant
+    # that fails or hangs (none of these collectives has met a second GPU from the authoring side) must not cost the run its
+    # headline: errors are recorded per variant, and a watchdog emits the line as it stands after SLAM_BENCH_DP_VARIANT_BUDGET_S
+    if dp_on and os.environ.get("SLAM_BENCH_DP_VARIANTS", "1") == "1":
+        import threading
+        rows = []
+
+        def bail():
+            if rank == 0:
+                out.setdefault("extras", {})["dp_variants"] = rows + [{"error": "watchdog: the variant table did not finish in time"}]
+                emit(out)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("SLAM_BENCH_DP_VARIANT_BUDGET_S", "120")), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            dp_variant_table(model, trainer, args, rank, world, dev, rows)
+        except Exception as e:  # noqa: BLE001 - recorded on the line
+            rows.append({"error": f"{type(e).__name__}: {e}"[:300]})
+        dog.cancel()
+        if rank == 0:
+            out.setdefault("extras", {})["dp_variants"] = rows
             out["extras"]["nccl_env"] = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO", "GPU_MAX_HW_QUEUES")}
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             del trainer, model
             torch.cuda.empty_cache()
