@@ -114,12 +114,14 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
             # L2-miss-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
-            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r4_pmc_step.md, row
-            # `gemm_nt_256_kernel<true> [256 blocks] fwd`: 229.1 MB read + 240.2 MB written), not collected live - counters
-            # need rocprofv3 around the process. The write side is exactly algorithmic (159.4 MB gate|up + 79.7 MB act);
-            # the read side is 7.1x the 32 MB of operands: each of the 8 XCD-private L2s streams the 17.4 MB weight (L2 misses,
-            # served by the 256 MB infinity cache after the first XCD: FETCH_SIZE is not HBM reads).
-            "traffic": 469.3e6, "traffic_source": "recorded: profiles/r4_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/one_step.py, the same persistent launch)",
+            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r5_pmc_step.md, row
+            # `gemm_nt_256_kernel<true, false> [256 blocks] fwd`: 233.3 MB read + 239.6 MB written; round 4: 229.1 + 240.2), NOT
+            # collected by this run - counters need rocprofv3 around the process (tools/pmc_step.sh). The write side is exactly
+            # algorithmic (159.4 MB gate|up + 79.7 MB act); the read side is 7.2x the 32 MB of operands: each of the 8 XCD-private
+            # L2s streams the 17.4 MB weight (L2 misses, served by the 256 MB infinity cache after the first XCD: FETCH_SIZE is
+            # not HBM reads).
+            "traffic": 472.9e6, "traffic_source": "RECORDED, not measured by this run: profiles/r5_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over "
+                                                  "tools/one_step.py, the same persistent launch, kernels of commit 634cd75 = this kernel unchanged since round 4)",
             "algorithmic_bytes": 271.2e6}
 
 
@@ -378,9 +380,9 @@ def extra_measurements(model, trainer, rank, dev, a):
 
 def dp_variant_table(model, trainer, args, rank, world, dev, rows):
     """N > 1 only, after the timed region (which stays ddp_algo = rs_ag, bf16 exchange, 4 layers per bucket): the one driver
-    run at N GPUs also decides the open data-parallel questions - 5 optimizer steps (after 2 warm-up steps)
-    of every exchange variant on the same model, max over ranks: ms per step and the exposed communication time of the last
-    step. Every variant is a fresh SLAMTrainer (its own reducer, bucket plan and optimizer state) on the same engine."""
+    run at N GPUs also decides the open data-parallel questions - 5 optimizer steps (after 3 warm-up steps)
+    of every exchange variant on the same model: the median step time (max over ranks) and the exposed communication time of
+    the last step. Every variant is a fresh SLAMTrainer (its own reducer, bucket plan and optimizer state) on the same engine."""
     import dataclasses
     from slamkit_amd.trainer import SLAMTrainer
     variants = [("rs_ag", "bfloat16", 4), ("all_reduce", "bfloat16", 4), ("rs_ag", "float32", 4), ("rs_ag", "bfloat16", 2), ("rs_ag", "bfloat16", 8),
@@ -394,18 +396,20 @@ def dp_variant_table(model, trainer, args, rank, world, dev, rows):
         a2 = dataclasses.replace(args, ddp_algo=algo, ddp_comm_dtype=cd, ddp_bucket_layers=bl, gradient_accumulation_steps=1)
         tr = SLAMTrainer(model=model, args=a2)
         nv = int(os.environ.get("SLAM_BENCH_DP_VARIANT_STEPS", "5"))
-        for _ in range(min(2, nv)):
+        for _ in range(min(3, nv)):  # the first steps of a fresh reducer allocate its staging buffers and set RCCL up for its message sizes
             tr.optimizer_step(batch, 1e-3, counts=(n_items, n_items))
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nv):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(nv + 1)]
+        ev[0].record()
+        for i in range(nv):
             tr.optimizer_step(batch, 1e-3, counts=(n_items, n_items))
+            ev[i + 1].record()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / nv * 1e3
+        dt = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(nv))[nv // 2]  # median step (this rank's stream), MAX over ranks below
         ex = tr.reducer.exposed_ms()
         if world > 1:
             t = torch.tensor([dt, ex], dtype=torch.float64, device=dev)

@@ -29,6 +29,7 @@ extern "C" {
 #define SLAM_EINVAL (-1)      /* bad argument / unsupported shape */
 #define SLAM_ESTATE (-2)      /* call order (e.g. backward without forward, unbound buffers) */
 #define SLAM_ENOMEM (-3)      /* bound workspace too small */
+#define SLAM_EUNSUPPORTED (-4) /* an optional run-time dependency is missing (slam_comm_*: librccl) */
 
 typedef struct SlamEngine SlamEngine;
 typedef void* slam_stream_t; /* hipStream_t */
@@ -100,6 +101,24 @@ int slam_forward(SlamEngine* h, const int64_t* ids, const int64_t* labels, const
  * bucket_layers = decoder layers per gradient bucket for the callback (<=0: one bucket). */
 int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_bucket_cb cb, void* user,
                   slam_stream_t stream);
+/* ---- engine-side gradient exchange (RCCL over xGMI) for a consumer without torch.distributed -----------------------------
+ * What DistributedDataParallel does for the reference (/root/reference config/training_args/default.yaml:18, cli/train.py:51,61;
+ * SURVEY.md §8a T10, §8b `slam_allreduce_grads_async`). One communicator per engine on the engine's device; RCCL is looked up at the
+ * first call (dlopen of librccl.so.1 - the copy the process already has is reused), SLAM_EUNSUPPORTED when it is absent.
+ *   rank 0: slam_comm_unique_id(id, 128) -> ship the 128 bytes to every rank -> each rank: slam_comm_init(h, id, rank, world)
+ *   per step: slam_backward(h, scale, bucket_layers, cb, ...) with a callback that calls
+ *             slam_allreduce_grads_async(h, offset, count, bf16, slam_bucket_stream(h) ? slam_bucket_stream(h) : stream)
+ *             -> slam_comm_finish(h, stream) -> slam_grad_norm / slam_adamw_step on `stream`.
+ * slam_allreduce_grads_async: grads[offset, offset + count) summed over the ranks (in place) on the engine's communication stream,
+ * ordered after everything enqueued so far on `ready`; it returns at once. bf16_exchange = 1: the bf16 image bound by
+ * slam_set_grad_image before that backward crosses the wire (half the bytes) and is widened back into the fp32 buffer.
+ * slam_comm_finish: `stream` waits for every exchange issued since the last finish. */
+#define SLAM_COMM_ID_BYTES 128
+int slam_comm_unique_id(void* id_out, int32_t bytes);
+int slam_comm_init(SlamEngine* h, const void* id, int32_t rank, int32_t world);
+int slam_comm_destroy(SlamEngine* h);
+int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int32_t bf16_exchange, slam_stream_t ready);
+int slam_comm_finish(SlamEngine* h, slam_stream_t stream);
 /* Valid inside a slam_bucket_cb call: the stream on which the reported range is complete - the consumer records its
  * "bucket ready" event THERE. NULL = the stream passed to slam_backward. With the weight-gradient stream on, the
  * intermediate buckets are complete on that engine-owned stream (which has also been ordered after the norm / bias

@@ -5,11 +5,14 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <dlfcn.h>
 #include <string.h>
 
 #include <string>
 #include <utility>
 #include <vector>
+
+#include <rccl/rccl.h>  // types only: the library is looked up at run time (slam_comm_*)
 
 #include "../../include/slam_engine.h"
 #include "kernels.h"
@@ -99,6 +102,13 @@ struct SlamEngine {
   std::vector<hipEvent_t> fam_ev;                 // pool, reused step after step
   std::vector<std::pair<int, size_t>> fam_marks;  // (family id, index of the pair's first event)
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
+  // engine-side gradient exchange (slam_comm_*): one RCCL communicator, one communication stream, an event pool
+  void* comm = nullptr;                 // ncclComm_t
+  int comm_world = 0;
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> comm_ev;
+  size_t comm_ev_used = 0;
+  bf16_t* last_grad_img = nullptr;      // the image the last slam_backward wrote (slam_allreduce_grads_async, bf16 exchange)
   std::vector<hipEvent_t> ev_w;  // per layer (+1 for the head / embedding): 4 main->side, 3 side->main
 
   ~SlamEngine() {
@@ -110,6 +120,8 @@ struct SlamEngine {
     for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
     for (hipEvent_t e : pw_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : tg_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : comm_ev) (void)hipEventDestroy(e);
+    if (comm_stream) { (void)hipStreamSynchronize(comm_stream); (void)hipStreamDestroy(comm_stream); }
   }
   // parameter ranges another stream is still writing (sharded optimizer: the bf16 parameter all-gather on the
   // communication stream): the next reader waits for the event right before its first read of the range
@@ -703,6 +715,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   // values (unsplit weight-gradient tiles, slab reduces, the norm / bias finish kernel) - no conversion pass over the buffer
   bf16_t* const IMG = h->grad_img;
   h->grad_img = nullptr;
+  h->last_grad_img = IMG;
   auto img = [&](int64_t off) -> bf16_t* { return IMG ? IMG + off : nullptr; };
 
   // weight-gradient launches: on the main stream, or (bwd_wgrad_stream) on the side stream `ws` behind an event that the
@@ -1047,6 +1060,125 @@ int slam_unpack_grads_bf16(SlamEngine* h, int64_t offset, int64_t count, const v
   if (!h || !src_bf16 || offset < 0 || count < 0 || offset + count > h->n_params || (offset & 3) || (count & 3)) return SLAM_EINVAL;
   if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
   if (count) CK(bf16_to_f32((const bf16_t*)src_bf16, h->grads + offset, (size_t)count, (hipStream_t)stream));
+  return SLAM_OK;
+}
+
+// ---- engine-side gradient exchange over RCCL (slam_allreduce_grads_async) -----------------------------------
+// Replaces, for a consumer WITHOUT torch.distributed, what accelerate's DDP wrapper does for the reference
+// (/root/reference config/training_args/default.yaml:18, cli/train.py:51,61: torchrun sets RANK / WORLD_SIZE, the HF Trainer
+// wraps the model in DistributedDataParallel). The Python trainer keeps issuing its collectives through torch.distributed
+// (slamkit_amd/trainer/dp.py): same RCCL underneath. RCCL is NOT a link-time dependency of the engine: it is looked up at the
+// first slam_comm_* call (the copy a host process has already loaded - torch's - is the one dlopen returns).
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.lib = nullptr;
+    }
+  }
+  return r.lib ? &r : nullptr;
+}
+}  // namespace
+
+int slam_comm_unique_id(void* id_out, int32_t bytes) {
+  if (!id_out || bytes < (int32_t)sizeof(ncclUniqueId)) return SLAM_EINVAL;
+  Rccl* r = rccl();
+  if (!r) return SLAM_EUNSUPPORTED;
+  ncclUniqueId id;
+  if (r->GetUniqueId(&id) != ncclSuccess) return SLAM_ESTATE;
+  memcpy(id_out, &id, sizeof(id));
+  return SLAM_OK;
+}
+
+int slam_comm_init(SlamEngine* h, const void* id, int32_t rank, int32_t world) {
+  if (!h || !id || world <= 0 || rank < 0 || rank >= world) return SLAM_EINVAL;
+  if (h->comm) return h->fail(SLAM_ESTATE, "communicator already initialised");
+  Rccl* r = rccl();
+  if (!r) return h->fail(SLAM_EUNSUPPORTED, "librccl.so.1 not found");
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclComm_t c = nullptr;
+  const ncclResult_t e = r->CommInitRank(&c, world, uid, rank);
+  if (e != ncclSuccess) return h->fail(SLAM_ESTATE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
+  if (!h->comm_stream) CK((int)hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  h->comm = c;
+  h->comm_world = world;
+  return SLAM_OK;
+}
+
+int slam_comm_destroy(SlamEngine* h) {
+  if (!h) return SLAM_EINVAL;
+  if (h->comm) {
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    Rccl* r = rccl();
+    if (r) (void)r->CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr;
+    h->comm_world = 0;
+  }
+  return SLAM_OK;
+}
+
+int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int32_t bf16_exchange, slam_stream_t ready) {
+  if (!h || offset < 0 || count < 0 || offset + count > h->n_params) return SLAM_EINVAL;
+  if (!h->comm) return h->fail(SLAM_ESTATE, "slam_comm_init first");
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  if (bf16_exchange && (!h->last_grad_img || (offset & 3) || (count & 3)))
+    return h->fail(SLAM_ESTATE, "bf16 exchange: bind an image with slam_set_grad_image before the backward (ranges in multiples of 4)");
+  if (!count) return SLAM_OK;
+  Rccl* r = rccl();
+  // communication stream behind the producers of the range
+  if (h->comm_ev_used == h->comm_ev.size()) {
+    hipEvent_t e;
+    CK((int)hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    h->comm_ev.push_back(e);
+  }
+  hipEvent_t ev = h->comm_ev[h->comm_ev_used++];
+  CK((int)hipEventRecord(ev, (hipStream_t)ready));
+  CK((int)hipStreamWaitEvent(h->comm_stream, ev, 0));
+  ncclResult_t e;
+  if (bf16_exchange) {
+    bf16_t* img = h->last_grad_img + offset;
+    e = r->AllReduce(img, img, (size_t)count, ncclBfloat16, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
+    if (e == ncclSuccess) CK(bf16_to_f32(img, h->grads + offset, (size_t)count, h->comm_stream));
+  } else {
+    e = r->AllReduce(h->grads + offset, h->grads + offset, (size_t)count, ncclFloat32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
+  }
+  if (e != ncclSuccess) return h->fail(SLAM_ESTATE, r->GetErrorString ? r->GetErrorString(e) : "ncclAllReduce failed");
+  return SLAM_OK;
+}
+
+int slam_comm_finish(SlamEngine* h, slam_stream_t stream) {
+  if (!h) return SLAM_EINVAL;
+  if (!h->comm_stream || !h->comm_ev_used) return SLAM_OK;
+  if (h->comm_ev_used == h->comm_ev.size()) {
+    hipEvent_t e;
+    CK((int)hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    h->comm_ev.push_back(e);
+  }
+  hipEvent_t ev = h->comm_ev[h->comm_ev_used];
+  CK((int)hipEventRecord(ev, h->comm_stream));
+  CK((int)hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+  h->comm_ev_used = 0;  // the pool is reused by the next step (events are re-recorded; the waits above were already enqueued)
   return SLAM_OK;
 }
 

@@ -86,6 +86,11 @@ def load_library(path: Optional[str] = None):
         "slam_add_param_wait": (C.c_int, [vp, i64, i64, vp]),
         "slam_param_wait_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "slam_param_wait_untimed": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "slam_comm_unique_id": (C.c_int, [vp, C.c_int32]),
+        "slam_comm_init": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
+        "slam_comm_destroy": (C.c_int, [vp]),
+        "slam_allreduce_grads_async": (C.c_int, [vp, i64, i64, C.c_int32, vp]),
+        "slam_comm_finish": (C.c_int, [vp, vp]),
         "slam_gateup_launch_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int32]),
         "slam_family_ms": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
         "slam_family_name": (C.c_char_p, [C.c_int32]),
@@ -357,6 +362,31 @@ class Engine:
     def unpack_grads_bf16(self, offset: int, count: int, src_bf16, stream=None):
         self._ck(self.lib.slam_unpack_grads_bf16(self.h, int(offset), int(count), _ptr(src_bf16),
                                                  stream if stream is not None else current_stream_ptr()))
+
+    # ---- engine-side gradient exchange (RCCL looked up at run time; include/slam_engine.h slam_comm_*) --------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and ships them to every rank)."""
+        buf = C.create_string_buffer(128)
+        rc = load_library().slam_comm_unique_id(buf, 128)
+        if rc != 0:
+            raise RuntimeError(f"slam_comm_unique_id failed with {rc}" + (" (librccl.so.1 not found)" if rc == -4 else ""))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        self._ck(self.lib.slam_comm_init(self.h, C.create_string_buffer(unique_id, 128), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.slam_comm_destroy(self.h))
+
+    def allreduce_grads_async(self, offset: int, count: int, bf16_exchange: bool = False, ready_stream=None):
+        """Sum grads[offset:offset+count] over the communicator on the engine's communication stream, after the work
+        enqueued so far on `ready_stream` (raw handle; None = torch's current stream)."""
+        self._ck(self.lib.slam_allreduce_grads_async(self.h, int(offset), int(count), int(bool(bf16_exchange)),
+                                                     ready_stream if ready_stream else current_stream_ptr()))
+
+    def comm_finish(self, stream=None):
+        self._ck(self.lib.slam_comm_finish(self.h, stream if stream is not None else current_stream_ptr()))
 
     def zero_grads(self, stream=None):
         self._ck(self.lib.slam_zero_grads(self.h, stream if stream is not None else current_stream_ptr()))

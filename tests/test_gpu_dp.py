@@ -319,3 +319,67 @@ def test_two_ranks_on_one_gpu_real_engine_sharded_equals_replicated(tmp_path, os
     assert abs(gn2 - gn1) <= (2e-3 if osd == "float32" else 2e-2) * gn1, (gn2, gn1)
     assert res[("float32", "all_reduce")]["grad_norm"] == gn2
     assert rel <= (2e-2 if osd == "float32" else 1e-1), rel
+
+
+ENGINE_COMM_WORKER = r'''
+import os, sys
+import torch
+sys.path.insert(0, os.environ["SLAM_ROOT"])
+from oracle import slam_oracle as O
+from slamkit_amd.engine import Engine
+from slamkit_amd.model import UnitLM, UnitLMConfig
+
+torch.cuda.set_device(0)
+cfg = O.TINY
+base = dict(num_hidden_layers=4, hidden_size=cfg.hidden, num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads,
+            head_dim=cfg.head_dim, intermediate_size=cfg.intermediate, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+            tie_word_embeddings=True)
+m = UnitLM(UnitLMConfig(base_model_name="local", base_config=base, vocab_size=cfg.vocab, max_tokens=512), seed=1)
+eng = m.engine
+g = torch.Generator().manual_seed(0)
+ids = torch.randint(2, cfg.vocab, (2, 128), generator=g)
+ids[:, 0] = 1
+
+def run(exchange, bf16):
+    m.zero_grad()
+    m(input_ids=ids, labels=ids, return_logits=False)
+    ranges = []
+    stage = None
+    if bf16:
+        stage = torch.full((eng.n_params,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        eng.set_grad_image(stage)
+    def cb(off, cnt, ready):
+        ranges.append((off, cnt))
+        if exchange:
+            eng.allreduce_grads_async(off, cnt, bf16, ready)
+    eng.set_option("grad_overwrite_next", 1)
+    eng.backward(1.0, 1, cb)
+    if exchange:
+        eng.comm_finish()
+    torch.cuda.synchronize()
+    return m.flat_grads.clone(), ranges, stage
+
+plain, ranges0, _ = run(False, False)
+eng.comm_init(Engine.comm_unique_id(), 0, 1)   # a 1-rank RCCL communicator: SUM is the identity
+f32, ranges1, _ = run(True, False)
+b16, ranges2, stage = run(True, True)
+eng.comm_destroy()
+assert ranges0 == ranges1 == ranges2 and sum(c for _, c in ranges0) == eng.n_params
+assert torch.equal(plain, f32), float((plain - f32).abs().max())
+assert torch.equal(b16, plain.to(torch.bfloat16).float()), float((b16 - plain).abs().max())
+assert torch.equal(stage.float(), b16)
+print("ENGINE_COMM_OK", len(ranges0))
+'''
+
+
+def test_engine_side_rccl_exchange_single_rank(tmp_path):
+    """slam_comm_* / slam_allreduce_grads_async (include/slam_engine.h): the gradient exchange of a consumer WITHOUT
+    torch.distributed - RCCL looked up by the engine at run time, one communicator per engine, collectives on the engine's
+    communication stream behind slam_bucket_stream. On a 1-rank communicator a SUM all-reduce is the identity: the fp32
+    exchange must leave the gradients of the plain backward bit for bit, the bf16 exchange (image written by backward,
+    all-reduced, widened back) their bf16 rounding; the callback's ranges tile [0, n_params)."""
+    w = tmp_path / "engine_comm_worker.py"
+    w.write_text(ENGINE_COMM_WORKER)
+    env = dict(os.environ, SLAM_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(w)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ENGINE_COMM_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
