@@ -389,12 +389,17 @@ def dp_variant_table(model, trainer, args, rank, world, dev, rows):
                 ("all_reduce", "bfloat16", 8)]
     n_items = float(B * T)
     batch = [synth_batch(rank, 200, dev)]
+    # ONE communication stream for every variant: each reducer would otherwise create its own, and streams beyond the HIP
+    # hardware queues (GPU_MAX_HW_QUEUES = 8) share a queue with the compute or the weight-gradient stream - measured on a
+    # 1-rank group: two of six variants 12 ms per step slower for no other reason
+    shared_side = trainer.reducer.side
     for algo, cd, bl in variants:
         model.engine.join()
         torch.cuda.synchronize()
         trainer.exp_avg = trainer.exp_avg_sq = None  # one optimizer state at a time
         a2 = dataclasses.replace(args, ddp_algo=algo, ddp_comm_dtype=cd, ddp_bucket_layers=bl, gradient_accumulation_steps=1)
         tr = SLAMTrainer(model=model, args=a2)
+        tr.reducer.side = shared_side
         nv = int(os.environ.get("SLAM_BENCH_DP_VARIANT_STEPS", "5"))
         for _ in range(min(3, nv)):  # the first steps of a fresh reducer allocate its staging buffers and set RCCL up for its message sizes
             tr.optimizer_step(batch, 1e-3, counts=(n_items, n_items))
