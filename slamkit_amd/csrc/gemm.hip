@@ -55,7 +55,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
       {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
+      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -94,6 +94,7 @@ struct GemmArgs {
   int rope_q_heads;
   int stagger_ticks;  // persistent 256 x 256 blocks with one tile fewer than the longest start this many 10-ns ticks late
   int cohorts;        // > 1: the slots of an XCD in this many contiguous cohorts, cohort c starts c * stagger_ticks late (every block)
+  int group_cols;     // > 0: tile rasterisation groups are group_rows x group_cols tiles (0 = group_rows x all columns)
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -934,13 +935,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     }
   }
   auto tile_origin = [&](int id, int& r0, int& c0) {
+    // bands of GR row tiles; inside a band, groups of GC column tiles (GC = all columns by default); inside a group column-major:
+    // the tiles in flight on one XCD share GR row panels and a few column panels, and with GC < tiles_c an XCD's whole range of
+    // tile ids touches only GC column panels of the weight (2-D partition of the tile space over the XCD-private L2s)
     const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = id / per_group, in = id - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    const int tc_ = in / rows_here;
-    r0 = (grp * GR + in - tc_ * rows_here) * 256;
-    c0 = tc_ * 256;
+    const int GC = p.group_cols > 0 ? min(p.group_cols, p.tiles_c) : p.tiles_c;
+    const int per_band = GR * p.tiles_c;
+    const int band = id / per_band, in = id - band * per_band;
+    const int rows_here = min(GR, p.tiles_r - band * GR);
+    const int cg = in / (rows_here * GC), in2 = in - cg * rows_here * GC;
+    const int tc_ = in2 / rows_here;
+    r0 = (band * GR + in2 - tc_ * rows_here) * 256;
+    c0 = (cg * GC + tc_) * 256;
   };
   int row0, col0;
   tile_origin(nid, row0, col0);
@@ -1203,13 +1209,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
   }
   if (nid >= nid_end) return;
   auto tile_origin = [&](int id, int& r0, int& c0) {
+    // bands of GR row tiles; inside a band, groups of GC column tiles (GC = all columns by default); inside a group column-major:
+    // the tiles in flight on one XCD share GR row panels and a few column panels, and with GC < tiles_c an XCD's whole range of
+    // tile ids touches only GC column panels of the weight (2-D partition of the tile space over the XCD-private L2s)
     const int GR = p.group_rows > 0 ? p.group_rows : 1;
-    const int per_group = GR * p.tiles_c;
-    const int grp = id / per_group, in = id - grp * per_group;
-    const int rows_here = min(GR, p.tiles_r - grp * GR);
-    const int tc_ = in / rows_here;
-    r0 = (grp * GR + in - tc_ * rows_here) * 256;
-    c0 = tc_ * 256;
+    const int GC = p.group_cols > 0 ? min(p.group_cols, p.tiles_c) : p.tiles_c;
+    const int per_band = GR * p.tiles_c;
+    const int band = id / per_band, in = id - band * per_band;
+    const int rows_here = min(GR, p.tiles_r - band * GR);
+    const int cg = in / (rows_here * GC), in2 = in - cg * rows_here * GC;
+    const int tc_ = in2 / rows_here;
+    r0 = (band * GR + in2 - tc_ * rows_here) * 256;
+    c0 = (cg * GC + tc_) * 256;
   };
   int row0, col0;
   tile_origin(nid, row0, col0);
@@ -2026,6 +2037,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.tiles_r = a.R / 256;
   a.tiles_c = a.Cn / 256;
   a.group_rows = T().group_rows_256;
+  a.group_cols = T().group_cols_256;
   a.nt_store = T().nt_store;
   a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)

@@ -53,3 +53,32 @@ def test_gemm_tn_workspace_covers_every_contraction_length():
         cap = lib.slam_op_gemm_tn_workspace(8192, N, K)
         for M in range(64, 8192 + 1, 64):
             assert lib.slam_op_gemm_tn_workspace(M, N, K) <= cap, (M, N, K)
+
+
+def test_c_consumer_compiles_against_the_header(tmp_path):
+    """include/slam_engine.h is plain C and tools/examples/c_dp_consumer.c - one data-parallel optimizer step of a consumer without
+    torch: forward, backward with the bucket callback calling slam_allreduce_grads_async, slam_comm_finish, clip, AdamW - still
+    matches it (compile only: gcc, C99, warnings as errors)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), "-c",
+                        os.path.join(root, "tools", "examples", "c_dp_consumer.c"), "-o", str(tmp_path / "c.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_address_arithmetic_of_the_32x32x16_gemm_paths():
+    """tools/layout_sim.py: the index arithmetic of gemm.hip's 32x32x16 main loops restated on labels - LDS-DMA placement ->
+    swizzled fragment reads -> MFMA lane maps -> epilogue32 columns - for the 128 x 128, the eight-wave 256 x 256 and the four-wave
+    256 x 256 kernel: every stored element is the product sum it should be, every ds_read_b128 lane group is conflict-free."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("layout_sim", os.path.join(root, "tools", "layout_sim.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.sim_128x128()
+    m.sim_256_8wave()
+    m.sim_256_4wave()
