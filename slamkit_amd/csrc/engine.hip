@@ -457,7 +457,7 @@ int adamw_model(SlamEngine* h, int mode, float* master, void* m, void* v, const 
 
 extern "C" {
 
-const char* slam_version(void) { return "slam-engine gfx950 r4"; }
+const char* slam_version(void) { return "slam-engine gfx950 r5"; }
 
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
