@@ -22,6 +22,12 @@ Extra objects on the line:
                  time against the 8 TB/s HBM peak; `extras` - GA = 16, the host boundary, and the fp32-master optimizer (the
                  headline runs the recipe's own bf16 optimizer state), measured after the timed region;
                  config.ms_per_step_median - median of the per-step HIP-event times.
+                 Round 5: `roofline.dominant_by_time` names the kernel with the most launch time per step beside the gate|up
+                 entry; `roofline.traffic` is a RECORDED counter figure (profile and commit in `traffic_source`);
+                 `config.ms_per_step_median_50` = median of 50 further steps after the timed region (SURVEY.md §8d protocol);
+                 `value_fp32_master_optimizer` = the step of rounds 1-3 (fp32 master + moments), like for like;
+                 N > 1: `extras.dp_variants` (all_reduce / rs_ag, bf16 / fp32 wire, 2 / 4 / 8 layers per bucket: median step and
+                 exposed communication time of each, measured after the timed region, under a watchdog) + `extras.nccl_env`.
   cpu_baseline - the fp32 CPU oracle (oracle/slam_oracle.py, a port of the reference step: it cannot run the
                  reference's cli/train.py itself) timed on this box's host cores on a bounded
                  sample (B=1, T=1024 fwd+bwd+clip+AdamW, median of 3 steps after a warm-up: 10-15 s of CPU work).
