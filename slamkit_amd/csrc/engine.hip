@@ -493,7 +493,10 @@ int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   return SLAM_OK;
 }
 
-void slam_engine_destroy(SlamEngine* h) { delete h; }
+void slam_engine_destroy(SlamEngine* h) {
+  if (h) (void)slam_comm_destroy(h);  // a communicator the caller did not release (needs RCCL's symbols: not the destructor's job)
+  delete h;
+}
 const char* slam_last_error(SlamEngine* h) { return h ? h->err.c_str() : "null engine"; }
 int64_t slam_param_count(SlamEngine* h) { return h ? h->n_params : 0; }
 int32_t slam_tensor_count(SlamEngine* h) { return h ? (int32_t)h->tensors.size() : 0; }
