@@ -392,14 +392,18 @@ def dp_variant_table(model, trainer, args, rank, world, dev, rows):
     import dataclasses
     from slamkit_amd.trainer import SLAMTrainer
     variants = [("rs_ag", "bfloat16", 4), ("all_reduce", "bfloat16", 4), ("rs_ag", "float32", 4), ("rs_ag", "bfloat16", 2), ("rs_ag", "bfloat16", 8),
-                ("all_reduce", "bfloat16", 8)]
+                ("all_reduce", "bfloat16", 8),
+                # the same exchange with the persistent 256 x 256 grids on 240 / 224 of the 256 CUs: do RCCL's kernels need CUs of their own?
+                ("rs_ag", "bfloat16", 4, 240), ("rs_ag", "bfloat16", 4, 224)]
     n_items = float(B * T)
     batch = [synth_batch(rank, 200, dev)]
     # ONE communication stream for every variant: each reducer would otherwise create its own, and streams beyond the HIP
     # hardware queues (GPU_MAX_HW_QUEUES = 8) share a queue with the compute or the weight-gradient stream - measured on a
     # 1-rank group: two of six variants 12 ms per step slower for no other reason
     shared_side = trainer.reducer.side
-    for algo, cd, bl in variants:
+    for algo, cd, bl, *rest in variants:
+        pcus = rest[0] if rest else 0
+        model.engine.set_option("gemm_256_persist_cus", pcus)
         model.engine.join()
         torch.cuda.synchronize()
         trainer.exp_avg = trainer.exp_avg_sq = None  # one optimizer state at a time
@@ -427,9 +431,10 @@ def dp_variant_table(model, trainer, args, rank, world, dev, rows):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, ex = float(t[0]), float(t[1])
         tr._gather_optimizer_state()
-        rows.append({"algo": algo, "comm_dtype": cd, "bucket_layers": bl, "ms_per_step": round(dt, 3), "exposed_comm_ms": round(ex, 3),
-                     "tokens_per_s": round(world * B * T / (dt * 1e-3), 1)})
+        rows.append({"algo": algo, "comm_dtype": cd, "bucket_layers": bl, "persistent_grid_cus": pcus or "all", "ms_per_step": round(dt, 3),
+                     "exposed_comm_ms": round(ex, 3), "tokens_per_s": round(world * B * T / (dt * 1e-3), 1)})
         trainer = tr
+    model.engine.set_option("gemm_256_persist_cus", 0)
 
 
 def usable_cores() -> int:

@@ -55,7 +55,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
       {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
+      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_256_persist_cus", &t->g256_persist_cus, 0, 4096}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -2023,8 +2023,8 @@ static bool use_256(const GemmArgs& a) {
 // 109.1 -> 104.7, LM head of the 152k vocabulary 6294 -> 6106; Slam-358M step 313.4 k -> 319.7 k tok/s (two pairs)
 // gemm_256_persist  (field of GemmTune, kernels.h)
 static int launch_256(GemmArgs a, hipStream_t st) {
-  static int cus = 0;
-  if (!cus) {
+  static int cus_dev = 0;
+  if (!cus_dev) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
@@ -2032,7 +2032,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-    cus = n & ~7;
+    cus_dev = n & ~7;
   }
   a.tiles_r = a.R / 256;
   a.tiles_c = a.Cn / 256;
@@ -2043,6 +2043,11 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
   a.cohorts = T().g256_cohorts;
   const int tiles = a.tiles_r * a.tiles_c;
+  // gemm_256_persist_cus > 0: the persistent grid leaves CUs free (a multiple of 8 blocks: one slot count per XCD) - under data
+  // parallelism RCCL's kernels need somewhere to start while 256 one-per-CU blocks hold every CU (bench.py extras.dp_variants)
+  const int cus_all = cus_dev;
+  const int want = T().g256_persist_cus > 0 ? (T().g256_persist_cus & ~7) : cus_all;
+  const int cus = want >= 8 && want < cus_all ? want : cus_all;
   const bool persist = T().g256_persist && tiles > cus && !a.bias && !a.resid && !a.rope_cos;
   if (T().mf32 && T().g256_w4 && persist) {  // four waves of 128 x 128, persistent
     static bool attr4 = false;

@@ -22,6 +22,7 @@ struct GemmTune {
   // their store bursts fall under the other blocks' K loops. Same box, interleaved: 24.88 / 24.95 ms vs 25.05 / 25.17 / 25.39
   int g256_stagger = 1200, g256_stagger_dswiglu = 1200;
   int group_cols_256 = 0;       // > 0: 256-row tile groups are group_rows_256 x group_cols_256 tiles (0 = all columns of a band)
+  int g256_persist_cus = 0;     // > 0: blocks of the persistent 256 x 256 grids (multiple of 8; 0 = one per CU): CUs left to RCCL under data parallelism
   int g256_cohorts = 0;         // > 1: start offsets for every persistent block, cohort c of the XCD's slots c * stagger late (probe)
   int shared = 0;               // the launches of this call share the GPU with the engine's wgrad stream (set inside slam_backward)
   int nt224 = 1, nt224_min_k = 2048;
