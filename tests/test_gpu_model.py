@@ -568,3 +568,57 @@ def test_configs3_full_depth_packed_vs_oracle():
     # to bf16 relative to a running max that depends on where a sequence falls against the 64-key tiles, so O - and with it
     # the loss - moves by bf16 rounding noise under the permutation (measured 1.7e-4 = 1.4e-5 relative at 28 layers).
     assert abs(l2 - l0) <= 5e-4 and rel_err(g2, g0) <= 6e-2 and cosine(g2, g0) >= 0.998
+
+
+def test_degenerate_batches_vs_oracle(tiny):
+    """Edge batches a data-parallel rank can meet (unit_lm.py:13-29 semantics, checked against the oracle):
+      * one row whose labels are ALL -100 beside a normal row (mean reduction and the num_items_in_batch form);
+      * a micro-batch with NO valid target at all under the num_items_in_batch form (the step's tokens sit on the other ranks):
+        loss exactly 0, every gradient exactly 0, nothing non-finite - the reference's `sum / num_items` gives the same;
+      * the shortest shapes: B = 1 with T = 2 (one target) and T = 1 (no target after the shift);
+      * a row of 1 real token followed by padding (attention over a single key)."""
+    cfg, sd, sd_bf, m = tiny
+    g = torch.Generator().manual_seed(5)
+
+    def run(ids, lab, am=None, n=None):
+        m.zero_grad()
+        out = m(input_ids=ids, attention_mask=am, labels=lab, **({"num_items_in_batch": n} if n is not None else {}))
+        m.backward()
+        torch.cuda.synchronize()
+        return out, {k: v.clone() for k, v in m.named_grads()}
+
+    ids = torch.randint(2, cfg.vocab, (2, 40), generator=g)
+    ids[:, 0] = 1
+    lab = ids.clone()
+    lab[1, :] = -100
+    for n in (None, 39):
+        out, grads = run(ids, lab, n=n)
+        l_ref, lg_ref, g_ref = O.forward_loss_grads(cfg, sd_bf, ids, lab, **({"num_items_in_batch": float(n)} if n else {}))
+        assert abs(float(out.loss) - float(l_ref)) <= 2e-2, (n, float(out.loss), float(l_ref))
+        check(f"one fully ignored row, num_items={n}: logits", out.logits.float().cpu(), lg_ref, 2e-2)
+        k = "lm.model.layers.0.mlp.down_proj.weight"
+        assert cosine(grads[k].cpu(), g_ref[k]) >= 0.999
+    # no valid target on this rank, the global count comes from elsewhere
+    lab0 = torch.full_like(ids, -100)
+    out, grads = run(ids, lab0, n=100)
+    assert float(out.loss) == 0.0
+    assert torch.isfinite(out.logits.float()).all()
+    for k, v in grads.items():
+        assert torch.isfinite(v).all() and float(v.abs().max()) == 0.0, k
+    # shortest shapes
+    for T in (2, 1):
+        i2 = torch.tensor([[1, 7][:T]])
+        out, grads = run(i2, i2.clone(), n=1)
+        l_ref, lg_ref, g_ref = O.forward_loss_grads(cfg, sd_bf, i2, i2.clone(), num_items_in_batch=1.0)
+        assert abs(float(out.loss) - float(l_ref)) <= 2e-2, (T, float(out.loss), float(l_ref))
+        check(f"B=1 T={T}: logits", out.logits.float().cpu(), lg_ref, 2e-2)
+        assert all(torch.isfinite(v).all() for v in grads.values())
+    # one real token, then padding
+    i3 = torch.tensor([[1, 0, 0, 0, 0, 0], [1, 9, 11, 13, 0, 0]])
+    am = torch.tensor([[1, 0, 0, 0, 0, 0], [1, 1, 1, 1, 0, 0]])
+    l3 = torch.where(am.bool(), i3, torch.full_like(i3, -100))
+    out, grads = run(i3, l3, am=am)
+    l_ref, lg_ref, g_ref = O.forward_loss_grads(cfg, sd_bf, i3, l3, attention_mask=am)
+    assert abs(float(out.loss) - float(l_ref)) <= 2e-2
+    check("single-token row: logits at valid positions", out.logits.float().cpu()[am.bool()], lg_ref[am.bool()], 2e-2)
+    assert all(torch.isfinite(v).all() for v in grads.values())
