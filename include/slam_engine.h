@@ -142,7 +142,13 @@ int slam_seq_loglik(SlamEngine* h, const int64_t* labels, int32_t B, int32_t T, 
 int slam_scale_loss_rows(SlamEngine* h, const float* seq_coef, int32_t B, int32_t T, slam_stream_t stream);
 
 /* ---- optimizer step: HF Trainer clip_grad_norm_ + torch AdamW --------------
- * norm_out: fp32 [2] device = {global grad norm, clip coefficient}. */
+ * norm_out: fp32 [2] device = {global grad norm, clip coefficient}.
+ * Where the gradients are read from follows the last slam_backward: the fp32 buffer of slam_bind_params, or - after a
+ * backward that ran under slam_set_option(h, "grad_final_next", 2) - the bf16 buffer given to slam_set_grad_image, which then
+ * holds the ONLY copy of the step's final gradient values (the reference's own gradient precision: bf16 parameters have
+ * bf16 .grad, /root/reference config/model/slam.yaml:9). After "grad_final_next" >= 1 slam_grad_norm adds the per-block sums
+ * of squares that backward's final-value stores emitted, in launch / block order (the same bits every run), instead of
+ * reading the buffer again. */
 int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t stream);
 int slam_adamw_step(SlamEngine* h, float* master_f32, float* exp_avg, float* exp_avg_sq, const float* norm_out,
                     double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
@@ -238,7 +244,11 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
  * chunks per key tile), "attn_prio" (wave priority by block length); with h = NULL they set the process default used by the
  * single-op entry points. "bwd_wgrad_cus" = N > 0: the weight-gradient stream is created with a CU mask of N CUs (a BLOCKING
  * stream: run the step on a non-default stream then). "grad_overwrite_next" = 1: the next slam_backward stores the gradients instead of adding to
- * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "bwd_wgrad_stream" (default
+ * them (first micro-batch of an optimizer step; no zeroing pass needed), then resets itself. "grad_final_next" = 1 | 2: the next
+ * slam_backward is the LAST of its optimizer step (HF Trainer: the micro-batch on which `sync_gradients` is true) - every kernel
+ * that stores a final gradient value also emits its block's sum of squares for slam_grad_norm; with 2 the final values are
+ * stored ONLY as bf16 into the slam_set_grad_image buffer (earlier micro-batches keep accumulating in fp32) and slam_grad_norm /
+ * slam_adamw_step* read them there; resets itself. "bwd_wgrad_stream" (default
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
  * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",

@@ -1,6 +1,10 @@
 """Build libslam_engine.so (gfx950) in-tree: hipcc per translation unit, then one shared link.
 
-Usage: python -m slamkit_amd.csrc.build [--force]
+Usage: python -m slamkit_amd.csrc.build [--force] [--probes]
+
+--probes builds lib/libslam_engine_probes.so with -DSLAM_PROBES instead: the ONLY build in which a GEMM can run without its
+output stores (gemm_nt_store bit 1) or with another steady-state vmcnt (-DSLAM_PROBE_VMCNT via SLAM_PROBE_CFLAGS). Only
+tools/probes/* load it (SLAM_ENGINE_LIB=...); the product library rejects those settings.
 """
 import os
 import subprocess
@@ -32,12 +36,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+PROBES_LIB = os.path.join(LIB_DIR, "libslam_engine_probes.so")
+
+
+def build(force=False, verbose=True, probes=False):
     os.makedirs(LIB_DIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_probes" if probes else "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     hipcc = _hipcc()
+    FLAGS = list(globals()["FLAGS"]) + (["-DSLAM_PROBES"] + os.environ.get("SLAM_PROBE_CFLAGS", "").split() if probes else [])
+    LIB = PROBES_LIB if probes else globals()["LIB"]
 
     def compile_one(src):
         s = os.path.join(HERE, src)
@@ -60,4 +69,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, probes="--probes" in sys.argv))

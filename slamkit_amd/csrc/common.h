@@ -46,6 +46,25 @@ SLAM_DEVICE float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum of squares of the two bf16 values packed in w (what pack_bf16x2 produced: the values a bf16 store keeps)
+SLAM_DEVICE float sq_bf16x2(uint32_t w) {
+  const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+  return a * a + b * b;
+}
+// *slot = sum of s over the block's threads: lanes by the xor butterfly, waves in wave order - the same bits every run.
+// `red`: WAVES floats of LDS nothing else touches at this point; EVERY thread of the block must call (one barrier inside).
+template <int WAVES>
+SLAM_DEVICE void block_sum_store(float s, float* red, float* slot) {
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) t += red[w];
+    *slot = t;
+  }
+}
 SLAM_DEVICE float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

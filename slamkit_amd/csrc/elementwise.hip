@@ -194,9 +194,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 
 // out[c] = (acc? out[c]:0) + sum_b part[b][c]; block = 16 columns x 16 row-slices, fixed order.
 // blockIdx.y selects one of several equally shaped instances (per-layer partial slabs finished together).
+// img_only / sumsq: GradSink semantics (kernels.h) - slot = blockIdx.y * gridDim.x + blockIdx.x
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nb, int N,
                                                             float* __restrict__ out, int accumulate,
-                                                            size_t part_stride, size_t out_stride, bf16_t* __restrict__ img) {
+                                                            size_t part_stride, size_t out_stride, bf16_t* __restrict__ img,
+                                                            int img_only, float* __restrict__ sumsq) {
   __shared__ float red[16][17];
   part += (size_t)blockIdx.y * part_stride;
   out += (size_t)blockIdx.y * out_stride;
@@ -208,13 +210,29 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     for (int b = sl; b < nb; b += 16) s += part[(size_t)b * N + c];
   red[sl][cl] = s;
   __syncthreads();
+  float sq = 0.f;
   if (sl == 0 && c < N) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cl];
     const float o = (accumulate ? out[c] : 0.f) + t;
-    out[c] = o;
-    if (img) img[c] = f32_to_bf16(o);
+    if (!img_only) { out[c] = o; sq = o * o; }
+    if (img) {
+      const bf16_t b = f32_to_bf16(o);
+      img[c] = b;
+      if (img_only) { const float r = bf16_to_f32(b); sq = r * r; }
+    }
+  }
+  if (sumsq) {  // the 16 column results of the block, added in column order
+    __syncthreads();
+    if (sl == 0) red[0][cl] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[0][k];
+      sumsq[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
   }
 }
 
@@ -664,7 +682,10 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x,
 // same chunk sums bit for bit; norm_finish_kernel adds them in fp64 in chunk order.
 constexpr int GRAD_CHUNK = 8192;
 constexpr int CHUNKS_PER_BLOCK = 16;  // a block walks 16 consecutive chunks (512 KB): fewer, longer blocks stream better
-__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, size_t n, size_t first_chunk, size_t n_chunks,
+// GT = float: the fp32 gradient buffer; GT = bf16_t: gradients kept in bf16 (same element order, so a value that is exactly
+// representable in bf16 gives the same chunk sum through either instantiation)
+template <typename GT>
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const GT* __restrict__ g, size_t n, size_t first_chunk, size_t n_chunks,
                                                            float* __restrict__ chunk_sums) {
   __shared__ float red[CHUNKS_PER_BLOCK][4];
   const size_t kb = (size_t)blockIdx.x * CHUNKS_PER_BLOCK;
@@ -675,7 +696,17 @@ __global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restri
 #pragma unroll
     for (int it = 0; it < GRAD_CHUNK / 1024; ++it) {  // all eight loads in flight before the first add
       const size_t i = lo + (size_t)(it * 256 + threadIdx.x) * 4;
-      v[it] = i < hi ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < hi) {
+        if constexpr (sizeof(GT) == 4) {
+          v[it] = *reinterpret_cast<const float4*>(g + i);
+        } else {
+          const uint2 w = *reinterpret_cast<const uint2*>(g + i);
+          v[it] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                              __uint_as_float(w.y & 0xffff0000u));
+        }
+      } else {
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     float s = 0.f;
 #pragma unroll
@@ -743,8 +774,10 @@ SLAM_DEVICE void adam_elem(float& p, float& m, float& v, float g, const AdamHype
 }
 // torch.optim.AdamW semantics on fp32 master weights; writes the bf16 working copy; optional
 // grad zeroing. Traffic: 30 B/param (fp32 g,p,m,v read; p,m,v + bf16 written), 34 with zeroing.
+// GT: storage type of the gradients (float, or bf16_t when the last backward kept its final values in bf16 only)
+template <typename GT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_t* __restrict__ pb,
-                                                    float* __restrict__ g, float* __restrict__ m,
+                                                    GT* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n,
                                                     const float* __restrict__ clip, float lr, float b1, float b2,
                                                     float eps, float wd, float bc1, float bc2_sqrt,
@@ -752,7 +785,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const float cs = clip ? clip[1] : 1.f;
-  float4 gv = *reinterpret_cast<float4*>(g + i);
+  float gl[4];
+  load4<GT>(g + i, gl);
+  const float4 gv = make_float4(gl[0], gl[1], gl[2], gl[3]);
   float4 pv = *reinterpret_cast<float4*>(p + i);
   float4 mv = *reinterpret_cast<float4*>(m + i);
   float4 vv = *reinterpret_cast<float4*>(v + i);
@@ -768,22 +803,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, bf16_
   o.x = pack_bf16x2(pa[0], pa[1]);
   o.y = pack_bf16x2(pa[2], pa[3]);
   *reinterpret_cast<uint2*>(pb + i) = o;
-  if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
+  if constexpr (sizeof(GT) == 4) {
+    if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
+  }
 }
 
 // The Slam recipe's optimizer precision (/root/reference config/model/slam.yaml:9 torch_dtype bfloat16 -> bf16 parameters
 // and bf16 Adam moments under torch.optim.AdamW(fused=True)): state is STORED in bf16, every update is computed in fp32
 // from the stored values and rounded once on the way back (torch's fused kernel: opmath fp32, exp_avg by lerp).
 // No fp32 master copy. Traffic: fp32 g read (4) + bf16 p, m, v read and written (12) = 16 B/param.
-__global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p, float* __restrict__ g,
+template <typename GT>
+__global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p, GT* __restrict__ g,
                                                          bf16_t* __restrict__ m, bf16_t* __restrict__ v, size_t n,
                                                          const float* __restrict__ clip, float lr, float b1, float b2,
                                                          float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i >= n) return;
   const float cs = clip ? clip[1] : 1.f;
-  float4 g0 = *reinterpret_cast<float4*>(g + i), g1 = *reinterpret_cast<float4*>(g + i + 4);
-  float ga[8] = {g0.x * cs, g0.y * cs, g0.z * cs, g0.w * cs, g1.x * cs, g1.y * cs, g1.z * cs, g1.w * cs};
+  float ga[8];
+  load4<GT>(g + i, ga);
+  load4<GT>(g + i + 4, ga + 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ga[j] *= cs;
   float pa[8], ma[8], va[8];
   unpack_bf16x8(*reinterpret_cast<const uint4*>(p + i), pa);
   unpack_bf16x8(*reinterpret_cast<const uint4*>(m + i), ma);
@@ -794,9 +835,11 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p,
   *reinterpret_cast<uint4*>(p + i) = pack_bf16x8(pa);
   *reinterpret_cast<uint4*>(m + i) = pack_bf16x8(ma);
   *reinterpret_cast<uint4*>(v + i) = pack_bf16x8(va);
-  if (zero_grad) {
-    *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
-    *reinterpret_cast<float4*>(g + i + 4) = make_float4(0, 0, 0, 0);
+  if constexpr (sizeof(GT) == 4) {
+    if (zero_grad) {
+      *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(g + i + 4) = make_float4(0, 0, 0, 0);
+    }
   }
 }
 
@@ -806,9 +849,9 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p,
 // tile is one contiguous 256 B (fp32) / 128 B (bf16) piece of each state array; the updated bf16 tile goes out row-major
 // (pb) and, through a padded LDS tile, column-major (pt[C][R]). Per-element arithmetic is the flat kernels' own.
 // MT = float / bf16_t: storage type of the Adam moments; MASTER: fp32 master weights (else the bf16 parameters ARE the state).
-template <typename MT, bool MASTER, int TC>  // tile = 64 rows x TC columns (TC = 64 or 128: 256 B or 512 B fp32 row segments)
+template <typename MT, bool MASTER, int TC, typename GT>  // tile = 64 rows x TC columns (TC = 64 or 128: 256 B or 512 B fp32 row segments)
 __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, bf16_t* __restrict__ pt,
-                                                         float* __restrict__ g, MT* __restrict__ m, MT* __restrict__ v, int R, int C,
+                                                         GT* __restrict__ g, MT* __restrict__ m, MT* __restrict__ v, int R, int C,
                                                          size_t batch_stride, const float* __restrict__ clip, AdamHyper h) {
   constexpr int TPR = TC / 4, RPP = 256 / TPR, NP = 64 / RPP;  // threads per row, rows per pass, passes
   __shared__ uint16_t T[TC][66];  // transposed bf16 tile: T[col][row], rows padded to 132 B
@@ -821,7 +864,7 @@ __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, 
     const int row = rr + RPP * i;
     const size_t idx = boff + (size_t)(r0 + row) * C + c0 + cc;
     float ga[4], pa[4], ma[4], va[4];
-    load4<float>(g + idx, ga);
+    load4<GT>(g + idx, ga);
     if (MASTER) load4<float>(p + idx, pa);
     else load4<bf16_t>(pb + idx, pa);
     load4<MT>(m + idx, ma);
@@ -832,7 +875,9 @@ __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, 
     store4(m + idx, ma);
     store4(v + idx, va);
     store4(pb + idx, pa);
-    if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
+    if constexpr (sizeof(GT) == 4) {
+      if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) T[cc + j][row] = (uint16_t)(pack_bf16x2(pa[j], 0.f) & 0xffffu);
   }
@@ -848,8 +893,8 @@ __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, 
   }
 }
 // the vectors between the matrices (norm weights, biases): count elements at a constant stride, grid.y = instances
-template <typename MT, bool MASTER>
-__global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, float* __restrict__ g,
+template <typename MT, bool MASTER, typename GT>
+__global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, GT* __restrict__ g,
                                                             MT* __restrict__ m, MT* __restrict__ v, size_t n, size_t stride,
                                                             const float* __restrict__ clip, AdamHyper h) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -857,7 +902,7 @@ __global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ 
   const size_t idx = (size_t)blockIdx.y * stride + i;
   const float cs = clip ? clip[1] : 1.f;
   float ga[4], pa[4], ma[4], va[4];
-  load4<float>(g + idx, ga);
+  load4<GT>(g + idx, ga);
   if (MASTER) load4<float>(p + idx, pa);
   else load4<bf16_t>(pb + idx, pa);
   load4<MT>(m + idx, ma);
@@ -868,7 +913,9 @@ __global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ 
   store4(m + idx, ma);
   store4(v + idx, va);
   store4(pb + idx, pa);
-  if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
+  if constexpr (sizeof(GT) == 4) {
+    if (h.zero_grad) *reinterpret_cast<float4*>(g + idx) = make_float4(0, 0, 0, 0);
+  }
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
@@ -879,6 +926,26 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   o.x = pack_bf16x2(v.x, v.y);
   o.y = pack_bf16x2(v.z, v.w);
   *reinterpret_cast<uint2*>(d + i) = o;
+}
+
+// the same conversion over blocks of GRAD_CHUNK elements, each emitting the sum of squares of the ROUNDED values it stored
+// (GradSink slot = block index): the image of a gradient tensor that had to be built in fp32 (embedding scatter)
+__global__ __launch_bounds__(256) void f32_to_bf16_sumsq_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n,
+                                                                float* __restrict__ sumsq) {
+  __shared__ float red[4];
+  const size_t lo = (size_t)blockIdx.x * GRAD_CHUNK;
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < GRAD_CHUNK / 1024; ++it) {
+    const size_t i = lo + (size_t)(it * 256 + threadIdx.x) * 4;
+    if (i < n) {
+      const float4 v = *reinterpret_cast<const float4*>(s + i);
+      const uint2 o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      *reinterpret_cast<uint2*>(d + i) = o;
+      ss += sq_bf16x2(o.x) + sq_bf16x2(o.y);
+    }
+  }
+  block_sum_store<4>(ss, red, sumsq + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, size_t n) {
@@ -940,8 +1007,9 @@ int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M,
 
 int rmsnorm_bwd_blocks(int M) { int b = (M + 15) / 16; return b > 512 ? 512 : (b < 1 ? 1 : b); }  // 2 blocks/CU
 
+// sink (nullable, with dw): how the final values of dw are kept (GradSink, kernels.h)
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img) {
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img, GradSink* sink) {
   if ((H & 7) || H > MAXC_LIMIT * 512) return -1;
   int nb = rmsnorm_bwd_blocks(M);
   switch ((H / 8 + 63) / 64) {
@@ -950,14 +1018,21 @@ int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float*
     case 3: rmsnorm_bwd_kernel<3><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
     default: rmsnorm_bwd_kernel<4><<<nb, 256, 0, st>>>(dy, x, w, rstd, dres, dx, part, M, H); break;
   }
-  if (dw) colsum_finish_kernel<<<(H + 15) / 16, 256, 0, st>>>(part, nb, H, dw, accumulate, 0, 0, dw_img);  // dw == null: caller finishes later
+  if (dw) return colsum_finish_many(part, 0, nb, H, dw, 0, 1, accumulate, st, dw_img, sink);  // dw == null: caller finishes later
   LAUNCH_RET();
 }
 // finish `count` equally shaped partial slabs in one launch: out[i] (+)= column sums of part[i]
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
-                       int accumulate, hipStream_t st, bf16_t* img) {
+                       int accumulate, hipStream_t st, bf16_t* img, GradSink* sink) {
   if (count <= 0) return 0;
-  colsum_finish_kernel<<<dim3((N + 15) / 16, count), 256, 0, st>>>(part, nb, N, out, accumulate, part_stride, out_stride, img);
+  const dim3 grid((N + 15) / 16, count);
+  if (sink) {
+    sink->used = (int)(grid.x * grid.y);
+    if (sink->img_only && !img) return -1;
+    if (sink->sumsq && sink->used > sink->cap) return -3;
+  }
+  colsum_finish_kernel<<<grid, 256, 0, st>>>(part, nb, N, out, accumulate, part_stride, out_stride, img, sink ? sink->img_only : 0,
+                                             sink ? sink->sumsq : nullptr);
   LAUNCH_RET();
 }
 
@@ -968,7 +1043,7 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulat
   int nb = colsum_blocks(M);
   dim3 grid((N / 8 + 15) / 16, nb);
   colsum_bf16_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, part);
-  if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0, nullptr);
+  if (out) colsum_finish_kernel<<<(N + 15) / 16, 256, 0, st>>>(part, nb, N, out, accumulate, 0, 0, nullptr, 0, nullptr);
   LAUNCH_RET();
 }
 
@@ -1054,12 +1129,15 @@ int scale_bf16(bf16_t* x, size_t n, float s, hipStream_t st) {
 }
 
 int grad_chunk_elems() { return GRAD_CHUNK; }
-// chunk sums of the chunk-aligned range [off, off + cnt) (cnt may end at n instead of a chunk boundary)
-int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st) {
+// chunk sums of the chunk-aligned range [off, off + cnt) (cnt may end at n instead of a chunk boundary); g_bf16: the
+// gradients are bf16_t at g, not float
+int grad_sumsq_chunks(const void* g, int g_bf16, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st) {
   if ((n & 3) || (off % GRAD_CHUNK) || off + cnt > n || (((off + cnt) % GRAD_CHUNK) && off + cnt != n)) return -1;
   if (cnt == 0) return 0;
   const size_t nc = (cnt + GRAD_CHUNK - 1) / GRAD_CHUNK;
-  sumsq_chunks_kernel<<<(unsigned)((nc + CHUNKS_PER_BLOCK - 1) / CHUNKS_PER_BLOCK), 256, 0, st>>>(g, n, off / GRAD_CHUNK, nc, chunk_sums);
+  const unsigned nb = (unsigned)((nc + CHUNKS_PER_BLOCK - 1) / CHUNKS_PER_BLOCK);
+  if (g_bf16) sumsq_chunks_kernel<bf16_t><<<nb, 256, 0, st>>>((const bf16_t*)g, n, off / GRAD_CHUNK, nc, chunk_sums);
+  else sumsq_chunks_kernel<float><<<nb, 256, 0, st>>>((const float*)g, n, off / GRAD_CHUNK, nc, chunk_sums);
   LAUNCH_RET();
 }
 int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st) {
@@ -1067,26 +1145,34 @@ int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_no
   LAUNCH_RET();
 }
 int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st) {
-  if (int r = grad_sumsq_chunks(g, n, 0, n, part, st)) return r;
+  if (int r = grad_sumsq_chunks(g, 0, n, 0, n, part, st)) return r;
   return grad_norm_from_chunks(part, (n + GRAD_CHUNK - 1) / GRAD_CHUNK, max_norm, out, st);
 }
-int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
+int adamw(float* p, bf16_t* pb, void* g, int g_bf16, float* m, float* v, size_t n, const float* clip, double lr, double b1,
           double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
   if (n & 3) return -1;
   // bias corrections in double like torch.optim.AdamW (python floats), then fp32 in the kernel
   float bc1 = (float)(1.0 - pow(b1, (double)step));
   float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
-  adamw_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
-                                                     (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  if (g_bf16)
+    adamw_kernel<bf16_t><<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, (bf16_t*)g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
+                                                              (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  else
+    adamw_kernel<float><<<nblocks(n / 4, 256), 256, 0, st>>>(p, pb, (float*)g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
+                                                             (float)eps, (float)wd, bc1, bc2s, zero_grad);
   LAUNCH_RET();
 }
-int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
+int adamw_bf16(bf16_t* p, void* g, int g_bf16, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
                double eps, double wd, int step, int zero_grad, hipStream_t st) {
   if (n & 7) return -1;
   float bc1 = (float)(1.0 - pow(b1, (double)step));
   float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
-  adamw_bf16_kernel<<<nblocks(n / 8, 256), 256, 0, st>>>(p, g, m, v, n, clip, (float)lr, (float)b1, (float)b2, (float)eps,
-                                                         (float)wd, bc1, bc2s, zero_grad);
+  if (g_bf16)
+    adamw_bf16_kernel<bf16_t><<<nblocks(n / 8, 256), 256, 0, st>>>(p, (bf16_t*)g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
+                                                                   (float)eps, (float)wd, bc1, bc2s, zero_grad);
+  else
+    adamw_bf16_kernel<float><<<nblocks(n / 8, 256), 256, 0, st>>>(p, (float*)g, m, v, n, clip, (float)lr, (float)b1, (float)b2,
+                                                                  (float)eps, (float)wd, bc1, bc2s, zero_grad);
   LAUNCH_RET();
 }
 static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int step, int zero_grad) {
@@ -1098,9 +1184,17 @@ static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double 
   h.zero_grad = zero_grad;
   return h;
 }
+template <int TC, typename GT>
+static void adamw_tiles_launch(int mode, dim3 grid, float* p, bf16_t* pb, bf16_t* pt, GT* g, void* m, void* v, int R, int C,
+                               size_t batch_stride, const float* clip, const AdamHyper& h, hipStream_t st) {
+  if (mode == 0) adamw_tile_kernel<float, true, TC, GT><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
+  else if (mode == 1) adamw_tile_kernel<bf16_t, true, TC, GT><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  else adamw_tile_kernel<bf16_t, false, TC, GT><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+}
 // mode 0: fp32 master + fp32 moments; 1: fp32 master + bf16 moments; 2: bf16 parameters + bf16 moments (no master)
-int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, void* v, int R, int C, int batch, size_t batch_stride,
-                const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
+int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, void* g, int g_bf16, void* m, void* v, int R, int C, int batch,
+                size_t batch_stride, const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad,
+                hipStream_t st) {
   if ((R & 63) || (C & 63) || batch < 1 || mode < 0 || mode > 2) return -1;
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, step, zero_grad);
   static int tile_cols = 128;  // SLAM_ADAMW_TILE_COLS=64: 256-byte row segments (A/B knob)
@@ -1108,26 +1202,30 @@ int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, v
   if (!read_env) { const char* e = getenv("SLAM_ADAMW_TILE_COLS"); if (e && atoi(e) == 64) tile_cols = 64; read_env = true; }
   if (tile_cols == 128 && (C % 128 == 0)) {
     const dim3 grid(C / 128, R / 64, batch);
-    if (mode == 0) adamw_tile_kernel<float, true, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
-    else if (mode == 1) adamw_tile_kernel<bf16_t, true, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
-    else adamw_tile_kernel<bf16_t, false, 128><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+    if (g_bf16) adamw_tiles_launch<128, bf16_t>(mode, grid, p, pb, pt, (bf16_t*)g, m, v, R, C, batch_stride, clip, h, st);
+    else adamw_tiles_launch<128, float>(mode, grid, p, pb, pt, (float*)g, m, v, R, C, batch_stride, clip, h, st);
   } else {
     const dim3 grid(C / 64, R / 64, batch);
-    if (mode == 0) adamw_tile_kernel<float, true, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (float*)m, (float*)v, R, C, batch_stride, clip, h);
-    else if (mode == 1) adamw_tile_kernel<bf16_t, true, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
-    else adamw_tile_kernel<bf16_t, false, 64><<<grid, 256, 0, st>>>(p, pb, pt, g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+    if (g_bf16) adamw_tiles_launch<64, bf16_t>(mode, grid, p, pb, pt, (bf16_t*)g, m, v, R, C, batch_stride, clip, h, st);
+    else adamw_tiles_launch<64, float>(mode, grid, p, pb, pt, (float*)g, m, v, R, C, batch_stride, clip, h, st);
   }
   LAUNCH_RET();
 }
-int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, size_t n, int batch, size_t stride, const float* clip,
-                  double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
+template <typename GT>
+static void adamw_strided_launch(int mode, dim3 grid, float* p, bf16_t* pb, GT* g, void* m, void* v, size_t n, size_t stride,
+                                 const float* clip, const AdamHyper& h, hipStream_t st) {
+  if (mode == 0) adamw_strided_kernel<float, true, GT><<<grid, 256, 0, st>>>(p, pb, g, (float*)m, (float*)v, n, stride, clip, h);
+  else if (mode == 1) adamw_strided_kernel<bf16_t, true, GT><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
+  else adamw_strided_kernel<bf16_t, false, GT><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
+}
+int adamw_strided(int mode, float* p, bf16_t* pb, void* g, int g_bf16, void* m, void* v, size_t n, int batch, size_t stride,
+                  const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st) {
   if ((n & 3) || batch < 1 || mode < 0 || mode > 2) return -1;
   if (n == 0) return 0;
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, step, zero_grad);
   const dim3 grid(nblocks(n / 4, 256), batch);
-  if (mode == 0) adamw_strided_kernel<float, true><<<grid, 256, 0, st>>>(p, pb, g, (float*)m, (float*)v, n, stride, clip, h);
-  else if (mode == 1) adamw_strided_kernel<bf16_t, true><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
-  else adamw_strided_kernel<bf16_t, false><<<grid, 256, 0, st>>>(p, pb, g, (bf16_t*)m, (bf16_t*)v, n, stride, clip, h);
+  if (g_bf16) adamw_strided_launch<bf16_t>(mode, grid, p, pb, (bf16_t*)g, m, v, n, stride, clip, h, st);
+  else adamw_strided_launch<float>(mode, grid, p, pb, (float*)g, m, v, n, stride, clip, h, st);
   LAUNCH_RET();
 }
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st) {
@@ -1138,6 +1236,12 @@ int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size
 int bf16_to_f32(const bf16_t* s, float* d, size_t n, hipStream_t st) {
   if (n & 3) return -1;
   bf16_to_f32_kernel<<<nblocks(n / 4, 256), 256, 0, st>>>(s, d, n);
+  LAUNCH_RET();
+}
+int f32_to_bf16_sumsq_slots(size_t n) { return (int)((n + GRAD_CHUNK - 1) / GRAD_CHUNK); }
+int f32_to_bf16_sumsq(const float* s, bf16_t* d, size_t n, float* sumsq, hipStream_t st) {
+  if (n & 3) return -1;
+  f32_to_bf16_sumsq_kernel<<<(unsigned)f32_to_bf16_sumsq_slots(n), 256, 0, st>>>(s, d, n, sumsq);
   LAUNCH_RET();
 }
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st) {

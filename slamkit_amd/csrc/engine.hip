@@ -72,6 +72,15 @@ struct SlamEngine {
   // the later layers runs under the MFMA-bound first layers of the next step
   bool overwrite_next = false;  // "grad_overwrite_next": the next backward stores gradients instead of adding to them
   bf16_t* grad_img = nullptr;   // slam_set_grad_image: the next backward also writes every final gradient value there, as bf16
+  // "grad_final_next" (round 6): the next backward is the LAST of its optimizer step. 1: every kernel that stores a final
+  // gradient value also emits the sum of squares of its block (GradSink, kernels.h) - slam_grad_norm adds ~60 k partials
+  // instead of reading the buffer again. 2: additionally the final values go to the bf16 image ONLY (the reference's own
+  // gradient precision, config/model/slam.yaml:9): slam_grad_norm / slam_adamw_* then read the image (2 B/param instead of 4).
+  int final_next = 0;
+  int gfinal = 0;               // what the last backward did (0: plain - gradients in `grads`, norm from chunk sums)
+  bf16_t* g16 = nullptr;        // gfinal == 2: where the gradients are
+  float* gn_part = nullptr;     // sum-of-squares partials of the last final backward
+  size_t gn_cap = 0, gn_used = 0;
   int overlap_adamw = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr;
@@ -240,6 +249,17 @@ size_t carve(SlamEngine* e, char* base, int64_t Mmax) {
   e->bias_ps = (size_t)colsum_blocks((int)M) * e->QKV;
   e->ln_part = c.take<float>(e->ln_ps * 2 * L);
   e->bias_part = c.take<float>(e->bias_ps * L);
+  {  // GradSink slots of one backward: every launch that stores final gradient values, under any plan
+    const size_t HD = (size_t)d.n_heads * d.head_dim;
+    size_t emb = gemm_tn_sumsq_slots(e->vpad, (int)H);
+    const size_t conv = (size_t)f32_to_bf16_sumsq_slots((size_t)e->vpad * H);
+    if (conv > emb) emb = conv;
+    const size_t per_layer = gemm_tn_sumsq_slots(e->QKV, (int)H) + gemm_tn_sumsq_slots((int)H, (int)HD) +
+                             gemm_tn_sumsq_slots((int)(2 * I), (int)H) + gemm_tn_sumsq_slots((int)H, (int)I) +
+                             2 * ((H + 15) / 16) + ((size_t)e->QKV + 15) / 16;
+    e->gn_cap = emb + L * per_layer + (H + 15) / 16 + 64;
+    e->gn_part = c.take<float>(e->gn_cap);
+  }
   e->scal = c.take<float>(64);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -425,15 +445,17 @@ int adamw_model(SlamEngine* h, int mode, float* master, void* m, void* v, const 
   const int L = d.n_layers, H = d.hidden, I = d.intermediate, HD = d.n_heads * d.head_dim;
   bf16_t* P = h->params;
   bf16_t* Pt = h->params_t;
-  float* G = h->grads;
+  const int g16 = h->gfinal == 2;  // the last backward kept its final values in bf16 only
+  char* G = g16 ? (char*)h->g16 : (char*)h->grads;
+  const size_t gsz = g16 ? 2 : 4;
   const size_t esz = mode == 0 ? 4 : 2;
   auto mat = [&](int64_t off, int R, int C, int batch) -> int {
-    return adamw_tiles(mode, master ? master + off : nullptr, P + off, Pt + off, G + off, (char*)m + off * esz, (char*)v + off * esz, R, C,
-                       batch, (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
+    return adamw_tiles(mode, master ? master + off : nullptr, P + off, Pt + off, G + off * gsz, g16, (char*)m + off * esz,
+                       (char*)v + off * esz, R, C, batch, (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
   };
   auto vec = [&](int64_t off, size_t n, int batch) -> int {
-    return adamw_strided(mode, master ? master + off : nullptr, P + off, G + off, (char*)m + off * esz, (char*)v + off * esz, n, batch,
-                         (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
+    return adamw_strided(mode, master ? master + off : nullptr, P + off, G + off * gsz, g16, (char*)m + off * esz, (char*)v + off * esz, n,
+                         batch, (size_t)h->layer_stride, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st);
   };
   int r = 0;
   if (chunk < 0 || chunk == 0) r = mat(h->off_embed, h->vpad, H, 1);
@@ -457,7 +479,7 @@ int adamw_model(SlamEngine* h, int mode, float* master, void* m, void* v, const 
 
 extern "C" {
 
-const char* slam_version(void) { return "slam-engine gfx950 r5"; }
+const char* slam_version(void) { return "slam-engine gfx950 r6"; }
 
 int slam_engine_create(const SlamModelDesc* desc, SlamEngine** out) {
   if (!desc || !out) return SLAM_EINVAL;
@@ -567,8 +589,9 @@ int slam_bind_workspace(SlamEngine* h, void* ws, size_t bytes, int64_t max_token
 int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   if (!key) return SLAM_EINVAL;
   if (!strncmp(key, "gemm_", 5)) {  // kernel-selection knobs: this engine's (h) or the process default's (h = NULL)
-    if (gemm_tune_set(h ? &h->gemm_tune : gemm_default_tune(), key, (long)value)) return SLAM_OK;
-    return h ? h->fail(SLAM_EINVAL, std::string("unknown option ") + key) : SLAM_EINVAL;
+    const int r = gemm_tune_set(h ? &h->gemm_tune : gemm_default_tune(), key, (long)value);
+    if (r > 0) return SLAM_OK;
+    return h ? h->fail(SLAM_EINVAL, std::string(r < 0 ? "value out of range for option " : "unknown option ") + key) : SLAM_EINVAL;
   }
   if (!strcmp(key, "attn_jq") || !strcmp(key, "attn_kw") || !strcmp(key, "attn_nch") || !strcmp(key, "attn_prio")) {
     // with an engine: that engine's launches (takes effect at its next forward, which rebuilds the attention plan);
@@ -593,6 +616,11 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   }
   if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "grad_final_next") && h) {
+    if (value < 0 || value > 2) return h->fail(SLAM_EINVAL, "grad_final_next takes 0, 1 or 2");
+    h->final_next = (int)value;
+    return SLAM_OK;
+  }
   if (!strcmp(key, "fuse_swiglu") && h) { h->fuse_swiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_dswiglu") && h) { h->fuse_dswiglu = value != 0; return SLAM_OK; }
   if (!strcmp(key, "fuse_adamw_t") && h) { h->fuse_adamw_t = value != 0; return SLAM_OK; }
@@ -720,6 +748,30 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->grad_img = nullptr;
   h->last_grad_img = IMG;
   auto img = [&](int64_t off) -> bf16_t* { return IMG ? IMG + off : nullptr; };
+  // last backward of an optimizer step ("grad_final_next"): sum-of-squares partials from the final-value stores, and
+  // (mode 2) final values in the bf16 image only. Every launch that stores final values takes its slots in launch order.
+  const int fin = h->final_next;
+  h->final_next = 0;
+  h->gfinal = 0;
+  h->g16 = nullptr;
+  if (fin == 2 && !IMG) return h->fail(SLAM_ESTATE, "grad_final_next = 2 needs slam_set_grad_image before the backward");
+  if (fin) {
+    CK((int)hipMemsetAsync(h->gn_part, 0, h->gn_cap * sizeof(float), st));  // blocks without a final store leave their slot alone
+    h->gn_used = 0;
+  }
+  GradSink sink_store;
+  auto sink = [&]() -> GradSink* {  // the slots from gn_used on; take(r) after the launch
+    if (!fin) return nullptr;
+    sink_store.img_only = fin == 2;
+    sink_store.sumsq = h->gn_part + h->gn_used;
+    sink_store.cap = (int)(h->gn_cap - h->gn_used);
+    sink_store.used = 0;
+    return &sink_store;
+  };
+  auto take = [&](int r) -> int {
+    if (fin && r == 0) h->gn_used += (size_t)sink_store.used;
+    return r;
+  };
 
   // weight-gradient launches: on the main stream, or (bwd_wgrad_stream) on the side stream `ws` behind an event that the
   // main stream records once their operands exist. Every cross-stream edge costs the recording AND the waiting stream a
@@ -751,18 +803,19 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   };
   auto fork = [&]() -> int { return two ? edge(st, ws) : 0; };
   // dW (+)= a^T b on a weight-gradient stream
-  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k, bf16_t* gi) -> int {
+  // is_final: the launch stores the tensor's final values (everything but the head's half of the tied embedding gradient)
+  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k, bf16_t* gi, bool is_final = true) -> int {
     if (int r = fork()) return r;
     const int slot = fam_begin(h, fam, ws);
-    const int r = gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, gi);
+    const int r = take(gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, gi, is_final ? sink() : nullptr));
     fam_end(h, slot, ws);
     return r;
   };
 
-  CK(wgrad(F_HEAD_WGRAD, h->dlogits, h->hf, G + h->off_embed, VP, H, nullptr));  // not final: the gather side adds to it below
+  CK(wgrad(F_HEAD_WGRAD, h->dlogits, h->hf, G + h->off_embed, VP, H, nullptr, false));  // not final: the gather side adds to it below
   TK(F_HEAD_DGRAD, st, dgrad(h->dlogits, h->off_embed, h->dx, VP, H));
   bf16_t* dh = h->dh_a;  // grad wrt hs[l+1]
-  TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st, img(h->off_norm)));
+  TK(F_NORM_BWD, st, take(rmsnorm_bwd(h->dx, h->hs[L], P + h->off_norm, h->rstdf, nullptr, dh, G + h->off_norm, acc, h->part_ws, M, H, st, img(h->off_norm), sink())));
 
   const int bl = bucket_layers > 0 ? bucket_layers : L;
   int64_t bucket_end = h->n_params;  // exclusive end of the not-yet-reported range
@@ -804,9 +857,9 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
       const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st, img(o.ln1)));
-      CK(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st, img(o.ln2)));
-      CK(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st, img(o.bqkv)));
+      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st, img(o.ln1), sink())));
+      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st, img(o.ln2), sink())));
+      CK(take(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st, img(o.bqkv), sink())));
       fin_hi = l;
     }
     if (boundary) {
@@ -827,18 +880,34 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     const int slot = fam_begin(h, F_EMBED_WGRAD, ws);
     if (VP == VPAD_SMALL) {
       CK(onehot(h->last_ids, h->onehot, M, VP, d.vocab, d.pad_token_id, ws));
-      CK(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, img(h->off_embed)));
+      CK(take(gemm_tn(h->onehot, dh, G + h->off_embed, 1, M, VP, H, VP, H, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, img(h->off_embed), sink())));
     } else {
       CK(embed_bwd(h->last_ids, dh, G + h->off_embed, M, H, VP, d.vocab, d.pad_token_id, h->embed_ws, ws));
       // the scatter only touches the rows that occur in the batch (the others keep the head's contribution): this one tensor
-      // gets its image from a conversion pass
-      if (IMG) CK(f32_to_bf16(G + h->off_embed, IMG + h->off_embed, (size_t)VP * H, ws));
+      // gets its image from a conversion pass (which also emits its partials when the values kept are the rounded ones)
+      const size_t ne = (size_t)VP * H;
+      if (fin == 2) {
+        const int slots = f32_to_bf16_sumsq_slots(ne);
+        if (h->gn_used + (size_t)slots > h->gn_cap) return h->fail(SLAM_ESTATE, "gradient-norm partial slots exhausted");
+        CK(f32_to_bf16_sumsq(G + h->off_embed, IMG + h->off_embed, ne, h->gn_part + h->gn_used, ws));
+        h->gn_used += (size_t)slots;
+      } else {
+        if (IMG) CK(f32_to_bf16(G + h->off_embed, IMG + h->off_embed, ne, ws));
+        if (fin == 1) {  // fp32 values kept: their chunk sums (the tensor starts the buffer: chunk-aligned, its end is `n` here)
+          const size_t slots = (ne + grad_chunk_elems() - 1) / grad_chunk_elems();
+          if (h->gn_used + slots > h->gn_cap) return h->fail(SLAM_ESTATE, "gradient-norm partial slots exhausted");
+          CK(grad_sumsq_chunks(G + h->off_embed, 0, ne, 0, ne, h->gn_part + h->gn_used, ws));
+          h->gn_used += slots;
+        }
+      }
     }
     fam_end(h, slot, ws);
   }
   if (two) CK(edge(ws, st));  // join: everything after slam_backward on `stream` sees complete gradients
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
+  h->gfinal = fin;
+  h->g16 = fin == 2 ? IMG : nullptr;
   return SLAM_OK;
 }
 
@@ -870,6 +939,10 @@ int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t
   if (!h || !norm_out) return SLAM_EINVAL;
   if (!h->grads || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");
   CK(join_optimizer(h, (hipStream_t)stream));
+  if (h->gfinal) {  // the last backward emitted the partial sums of squares with its final-value stores: add them, in slot order
+    CK(grad_norm_from_chunks(h->gn_part, h->gn_used, max_norm, norm_out, (hipStream_t)stream));
+    return SLAM_OK;
+  }
   CK(grad_norm(h->grads, (size_t)h->n_params, max_norm, h->part_ws, norm_out, (hipStream_t)stream));
   return SLAM_OK;
 }
@@ -883,15 +956,20 @@ static int adamw_any(SlamEngine* h, int mode, float* master, void* m, void* v, c
   CK(join_optimizer(h, st));
   CK(join_params(h, st));
   const bool fused = h->params_t != nullptr && h->fuse_adamw_t;
+  const int g16 = h->gfinal == 2;  // the last backward kept its final values in bf16 only (slam_set_grad_image's buffer)
+  char* const G = g16 ? (char*)h->g16 : (char*)h->grads;
+  const size_t gsz = g16 ? 2 : 4;
+  // zeroing belongs to the fp32 accumulation buffer: the kernels cannot do it while they read the bf16 image
+  if (g16 && zero_grad) CK((int)hipMemsetAsync(h->grads, 0, (size_t)h->n_params * sizeof(float), st));
   if (!h->overlap_adamw || mode != 0) {
     if (fused) {
       CK(adamw_model(h, mode, master, m, v, norm_out, lr, b1, b2, eps, wd, step, zero_grad, -1, st));
       h->params_t_dirty = false;
       return SLAM_OK;
     }
-    if (mode == 0) CK(adamw(master, h->params, h->grads, (float*)m, (float*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
-    else if (mode == 2) CK(adamw_bf16(h->params, h->grads, (bf16_t*)m, (bf16_t*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
-    else CK(adamw_strided(1, master, h->params, h->grads, m, v, (size_t)h->n_params, 1, 0, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    if (mode == 0) CK(adamw(master, h->params, G, g16, (float*)m, (float*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    else if (mode == 2) CK(adamw_bf16(h->params, G, g16, (bf16_t*)m, (bf16_t*)v, (size_t)h->n_params, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    else CK(adamw_strided(1, master, h->params, G, g16, m, v, (size_t)h->n_params, 1, 0, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
     return slam_refresh_transposed(h, stream);
   }
   // "overlap_adamw" (fp32 state): per-layer chunks on the engine's side stream; the next forward waits per layer
@@ -907,7 +985,7 @@ static int adamw_any(SlamEngine* h, int mode, float* master, void* m, void* v, c
     } else {
       const int64_t lo = c == 0 ? 0 : c <= L ? h->lo[c - 1].ln1 : h->off_norm;
       const int64_t hi = c == 0 ? h->lo[0].ln1 : c < L ? h->lo[c].ln1 : c == L ? h->off_norm : h->n_params;
-      CK(adamw(master + lo, h->params + lo, h->grads + lo, (float*)m + lo, (float*)v + lo, (size_t)(hi - lo), norm_out, lr, b1, b2, eps, wd, step,
+      CK(adamw(master + lo, h->params + lo, G + lo * gsz, g16, (float*)m + lo, (float*)v + lo, (size_t)(hi - lo), norm_out, lr, b1, b2, eps, wd, step,
                zero_grad, h->side));
       if (Pt) {
         const bf16_t* P = h->params;
@@ -951,7 +1029,7 @@ int64_t slam_grad_chunk_elems(void) { return grad_chunk_elems(); }
 int slam_grad_sumsq_chunks(SlamEngine* h, int64_t offset, int64_t count, float* chunk_sums, slam_stream_t stream) {
   if (!h || !chunk_sums || offset < 0 || count < 0) return SLAM_EINVAL;
   if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
-  int r = grad_sumsq_chunks(h->grads, (size_t)h->n_params, (size_t)offset, (size_t)count, chunk_sums, (hipStream_t)stream);
+  int r = grad_sumsq_chunks(h->grads, 0, (size_t)h->n_params, (size_t)offset, (size_t)count, chunk_sums, (hipStream_t)stream);
   if (r < 0) return h->fail(SLAM_EINVAL, "range must start on a chunk boundary and end on one (or at the end of the buffer)");
   CK(r);
   return SLAM_OK;
@@ -973,7 +1051,7 @@ int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw(master, h->params + offset, h->grads + offset, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    CK(adamw(master, h->params + offset, h->grads + offset, 0, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
 }
@@ -987,7 +1065,7 @@ int slam_adamw_range_bf16_moments(SlamEngine* h, int64_t offset, int64_t count, 
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw_strided(1, master, h->params + offset, h->grads + offset, m_bf16, v_bf16, (size_t)count, 1, 0, norm_out, lr, b1, b2, eps, wd,
+    CK(adamw_strided(1, master, h->params + offset, h->grads + offset, 0, m_bf16, v_bf16, (size_t)count, 1, 0, norm_out, lr, b1, b2, eps, wd,
                      step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
@@ -1002,7 +1080,7 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* m_
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw_bf16(h->params + offset, h->grads + offset, (bf16_t*)m_bf16, (bf16_t*)v_bf16, (size_t)count, norm_out, lr, b1, b2, eps,
+    CK(adamw_bf16(h->params + offset, h->grads + offset, 0, (bf16_t*)m_bf16, (bf16_t*)v_bf16, (size_t)count, norm_out, lr, b1, b2, eps,
                   wd, step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;

@@ -44,11 +44,23 @@ static thread_local GemmTune* t_cur_tune = nullptr;
 GemmTune* gemm_default_tune() { return &g_default_tune; }
 GemmTune* gemm_use_tune(GemmTune* t) { GemmTune* old = t_cur_tune; t_cur_tune = t; return old; }
 GemmTune& T() { return t_cur_tune ? *t_cur_tune : g_default_tune; }
+// The shipped library has no way to run a GEMM without its output stores: bit 1 of gemm_nt_store (the no-store probe of
+// tools/probes/epilogue_cost.py / store_pmc.py) and the SLAM_PROBE_VMCNT override exist only in a -DSLAM_PROBES build
+// (`python -m slamkit_amd.csrc.build --probes` -> lib/libslam_engine_probes.so, which only tools/probes/* load).
+#ifdef SLAM_PROBES
+#define SLAM_NOSTORE(nt) ((nt) & 2)
+constexpr long NT_STORE_MAX = 3;
+#else
+#define SLAM_NOSTORE(nt) false
+constexpr long NT_STORE_MAX = 1;
+#endif
+// 1 = set, 0 = unknown key, -1 = value outside the option's range (strict options only; the others clamp)
 int gemm_tune_set(GemmTune* t, const char* key, long v) {
   auto clamp = [](long x, long lo, long hi) { return (int)(x < lo ? lo : x > hi ? hi : x); };
+  if (!strcmp(key, "gemm_nt_store") && (v < 0 || v > NT_STORE_MAX)) return -1;
   struct { const char* k; int* f; long lo, hi; } tab[] = {
       {"gemm_glds", &t->glds, 0, 1}, {"gemm_tn_dma", &t->tn_dma, 0, 1}, {"gemm_group_rows", &t->group_rows, 1, 64},
-      {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, 3},
+      {"gemm_tn_splits", &t->tn_splits_override, 0, 64}, {"gemm_nt_store", &t->nt_store, 0, NT_STORE_MAX},
       {"gemm_256_persist", &t->g256_persist, 0, 1}, {"gemm_256", &t->g256, 0, 2}, {"gemm_nt224", &t->nt224, 0, 2},
       {"gemm_nt224_min_k", &t->nt224_min_k, 0, 1 << 30}, {"gemm_256_dswiglu", &t->g256_dswiglu, 0, 1},
       {"gemm_group_rows_256", &t->group_rows_256, 1, 64}, {"gemm_tn_balanced", &t->tn_balanced, 0, 1}, {"gemm_tn224", &t->tn224, 0, 2},
@@ -100,7 +112,7 @@ struct GemmArgs {
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 SLAM_DEVICE void st_out(bf16_t* ptr, const uint4& v, int nt) {
   u32x4_t w = {v.x, v.y, v.z, v.w};
-  if (nt & 2) return;  // probe only (tools/probes/epilogue_cost.py): the launch without its output stores
+  if (SLAM_NOSTORE(nt)) return;  // -DSLAM_PROBES builds only (tools/probes/epilogue_cost.py): the launch without its output stores
   if (nt) __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(ptr));
   else *reinterpret_cast<u32x4_t*>(ptr) = w;
 }
@@ -307,7 +319,7 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
           du[e] = d * gv[e] * sg;
           dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
         }
-        if (mok && !(p.nt_store & 2)) {
+        if (mok && !SLAM_NOSTORE(p.nt_store)) {
           bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
           *reinterpret_cast<uint4*>(gp) = pack_bf16x8(dg);
           *reinterpret_cast<uint4*>(gp + 32) = pack_bf16x8(du);
@@ -430,7 +442,7 @@ SLAM_DEVICE void epilogue32(const GemmArgs& p_, const f32x16_t (&acc)[2][2], int
             du[e] = d * gv[e] * sg;
             dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
           }
-          if (mok && !(p.nt_store & 2)) {
+          if (mok && !SLAM_NOSTORE(p.nt_store)) {
             *reinterpret_cast<uint4*>(gp + 8 * u) = pack_bf16x8(dg);
             *reinterpret_cast<uint4*>(gp + 32 + 8 * u) = pack_bf16x8(du);
           }
@@ -880,7 +892,8 @@ template <bool LAST>
 SLAM_DEVICE void wait_ph(int which) {
   // outstanding half-tiles (2 DMAs each) allowed after the wait: 2 in steady state, fewer on the last K-tile
   // (SLAM_PROBE_VMCNT: a stricter steady-state count for the prefetch-depth probe of tools/probes/depth_probe.sh)
-#ifndef SLAM_PROBE_VMCNT
+#if !defined(SLAM_PROBES) || !defined(SLAM_PROBE_VMCNT)
+#undef SLAM_PROBE_VMCNT
 #define SLAM_PROBE_VMCNT 4
 #endif
   if (which == 0) { if (LAST) wait_vmcnt<2>(); else wait_vmcnt<SLAM_PROBE_VMCNT>(); }
@@ -1401,6 +1414,9 @@ struct BalArgs {
   int accumulate;
   size_t slab_stride;
   bf16_t* img;  // nullable: bf16 image of dW (same indexing), written together with every FINAL value of dW
+  float* sumsq;      // nullable: GradSink slots of the GEMM kernel's blocks ...
+  float* sumsq_red;  // ... and of reduce_bal_kernel's (y-major)
+  int img_only;      // final values go to img only (GradSink)
 };
 SLAM_DEVICE void bal_tile_rc(int t, int tiles_r, int tiles_c, int group_rows, int& tr_, int& tc_) {
   const int GR = group_rows > 0 ? group_rows : 1;
@@ -1494,6 +1510,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bal_kernel(BalArgs p) {
   }
   const bool add = direct && p.accumulate;
   bf16_t* const imgt = (direct && p.img) ? p.img + (dst - p.dW) : nullptr;  // unsplit tile: this store is the final value
+  const bool st32 = !(direct && p.img_only);  // a final value that is kept in bf16 only
+  float ss = 0.f;
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
     const size_t ro = (size_t)(wm * 64 + fm * 16 + l15) * stride + wn * 64 + g * 4;
@@ -1508,14 +1526,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bal_kernel(BalArgs p) {
       f32x4_t v = acc[fm][fn];
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
       if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
-      *reinterpret_cast<float4*>(row + fn * 16) = o;
-      if (imgt) *reinterpret_cast<uint2*>(imgt + ro + fn * 16) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      if (st32) *reinterpret_cast<float4*>(row + fn * 16) = o;
+      if (imgt) {
+        const uint2 w = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        *reinterpret_cast<uint2*>(imgt + ro + fn * 16) = w;
+        if (!st32) ss += sq_bf16x2(w.x) + sq_bf16x2(w.y);
+      }
+      if (st32) ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
     }
   }
+  if (p.sumsq)  // smem + 2 stages: 16 B the main loop never touches
+    block_sum_store<4>(direct ? ss : 0.f, reinterpret_cast<float*>(smem + 2 * STAGE_BYTES), p.sumsq + blockIdx.x);
 }
 
 // dW tile t (+)= its pieces in order; grid (16, tiles), thread = 4 consecutive columns
 __global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actual, int SB_actual) {
+  __shared__ float red[4];
   const int t = blockIdx.y;
   if (t < p.T_A && p.S_A == 1) return;  // accumulated in place by the GEMM
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1537,10 +1563,18 @@ __global__ __launch_bounds__(256) void reduce_bal_kernel(BalArgs p, int SA_actua
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
-  *reinterpret_cast<float4*>(p.dW + off) = s;
-  if (p.img) *reinterpret_cast<uint2*>(p.img + off) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+  float ss = 0.f;
+  if (!p.img_only) {
+    *reinterpret_cast<float4*>(p.dW + off) = s;
+    ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+  }
+  if (p.img) {
+    const uint2 w = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+    *reinterpret_cast<uint2*>(p.img + off) = w;
+    if (p.img_only) ss = sq_bf16x2(w.x) + sq_bf16x2(w.y);
+  }
+  if (p.sumsq_red) block_sum_store<4>(ss, red, p.sumsq_red + (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
-
 
 
 // ---- NT GEMM on 256 x 224 tiles, 8 waves, 8-phase schedule (dgrad launches with N = 896 under the two-stream backward) ------
@@ -1732,6 +1766,9 @@ struct Tn224Args {
   int T_A, S_A, per_A, T_B, S_B, per_B, nA;
   int accumulate;
   bf16_t* img;  // nullable: bf16 image of dW (same indexing), written with every FINAL value of dW
+  float* sumsq;      // nullable: GradSink slots of the GEMM kernel's blocks ...
+  float* sumsq_red;  // ... and of reduce_224_kernel's (y-major)
+  int img_only;      // final values go to img only (GradSink)
 };
 SLAM_DEVICE void tn224_tile(int t, int tiles_b, int& ta, int& tb) { ta = t / tiles_b; tb = t - ta * tiles_b; }
 
@@ -1913,7 +1950,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
     base = p.slab + slab_idx * (size_t)(256 * 224);
     ld = TR ? 256 : 224;
   }
-  bf16_t* const imgt = (direct && pieces == 1 && p.img) ? p.img + (base - p.dW) : nullptr;  // unsplit tile: final values
+  const bool fin = direct && pieces == 1;  // unsplit tile: these stores are the final values
+  bf16_t* const imgt = (fin && p.img) ? p.img + (base - p.dW) : nullptr;
+  const bool st32 = !(fin && p.img_only);  // a final value that is kept in bf16 only
+  float ss = 0.f;
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
     float4 old[7];
@@ -1930,15 +1970,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_224_kernel(Tn224Args p) {
       const f32x4_t v = acc[fm][fn];
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
       if (add) { o.x += old[fn].x; o.y += old[fn].y; o.z += old[fn].z; o.w += old[fn].w; }
-      *reinterpret_cast<float4*>(ptr[fn]) = o;
-      if (imgt) *reinterpret_cast<uint2*>(imgt + (ptr[fn] - base)) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      if (st32) *reinterpret_cast<float4*>(ptr[fn]) = o;
+      if (imgt) {
+        const uint2 w = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        *reinterpret_cast<uint2*>(imgt + (ptr[fn] - base)) = w;
+        if (!st32) ss += sq_bf16x2(w.x) + sq_bf16x2(w.y);
+      }
+      if (st32) ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
     }
   }
+  if (p.sumsq)  // smem + KT * 2: 32 B behind the two K-tile buffers (the barrier counts of the wave columns are balanced here)
+    block_sum_store<8>(fin ? ss : 0.f, reinterpret_cast<float*>(smem + 8 * 64 * 256), p.sumsq + blockIdx.x);
 }
 
 // dW tile t += its slabs (pieces 1..S-1) in piece order; grid (56, tiles): thread = 4 consecutive tile-local elements
 template <bool TR>
 __global__ __launch_bounds__(256) void reduce_224_kernel(Tn224Args p, int SA_act, int SB_act) {
+  __shared__ float red[4];
   const int t = blockIdx.y;
   const bool inA = t < p.T_A;
   const int S = inA ? SA_act : SB_act;
@@ -1956,22 +2004,43 @@ __global__ __launch_bounds__(256) void reduce_224_kernel(Tn224Args p, int SA_act
     const float4 v = *reinterpret_cast<const float4*>(src + k * stride);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  *reinterpret_cast<float4*>(dst) = s;
-  if (p.img) *reinterpret_cast<uint2*>(p.img + (dst - p.dW)) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+  float ss = 0.f;
+  if (!p.img_only) {
+    *reinterpret_cast<float4*>(dst) = s;
+    ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+  }
+  if (p.img) {
+    const uint2 w = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+    *reinterpret_cast<uint2*>(p.img + (dst - p.dW)) = w;
+    if (p.img_only) ss = sq_bf16x2(w.x) + sq_bf16x2(w.y);
+  }
+  if (p.sumsq_red) block_sum_store<4>(ss, red, p.sumsq_red + (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32, deterministic split-K finish)
-__global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
-                                     int splits, int accumulate, bf16_t* __restrict__ img) {
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
+                                                            int splits, int accumulate, bf16_t* __restrict__ img,
+                                                            int img_only, float* __restrict__ sumsq) {
+  __shared__ float red[4];
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
-  for (int k = 0; k < splits; ++k) {
-    float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  float ss = 0.f;
+  if (i < n) {
+    float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+    for (int k = 0; k < splits; ++k) {
+      float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (!img_only) {
+      *reinterpret_cast<float4*>(out + i) = s;
+      ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+    }
+    if (img) {
+      const uint2 w = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+      *reinterpret_cast<uint2*>(img + i) = w;
+      if (img_only) ss = sq_bf16x2(w.x) + sq_bf16x2(w.y);
+    }
   }
-  *reinterpret_cast<float4*>(out + i) = s;
-  if (img) *reinterpret_cast<uint2*>(img + i) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+  if (sumsq) block_sum_store<4>(ss, red, sumsq + blockIdx.x);
 }
 
 // nt_store  (field of GemmTune, kernels.h)
@@ -2284,11 +2353,12 @@ static size_t tn224_workspace_bytes(int Mmax, int N, int K) {
   return (size_t)slabs * 256 * 224 * sizeof(float);
 }
 static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-                        float* ws, int orient, int background, hipStream_t st, bf16_t* img) {
+                        float* ws, int orient, int background, hipStream_t st, bf16_t* img, GradSink* sink) {
+  constexpr int LDS = 8 * 64 * 256 + 64;  // two K-tile buffers + the block-sum scratch of the GradSink epilogue
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_224_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
@@ -2304,11 +2374,19 @@ static int launch_tn224(const bf16_t* dY, const bf16_t* X, float* dW, int accumu
   a.img = img;
   const int nblk = a.nA + pl.T_B * pl.S_B;
   const int T = pl.T_A + pl.T_B;
+  if (sink) {
+    sink->used = nblk + (pl.slabs ? 56 * T : 0);
+    if (sink->img_only && !img) return -1;
+    if (sink->sumsq && sink->used > sink->cap) return -3;
+    a.img_only = sink->img_only;
+    a.sumsq = sink->sumsq;
+    a.sumsq_red = sink->sumsq ? sink->sumsq + nblk : nullptr;
+  }
   if (pl.tr) {
-    gemm_tn_224_kernel<true><<<nblk, 512, 8 * 64 * 256, st>>>(a);
+    gemm_tn_224_kernel<true><<<nblk, 512, LDS, st>>>(a);
     if (pl.slabs) reduce_224_kernel<true><<<dim3(56, T), 256, 0, st>>>(a, pl.S_A, pl.S_B);
   } else {
-    gemm_tn_224_kernel<false><<<nblk, 512, 8 * 64 * 256, st>>>(a);
+    gemm_tn_224_kernel<false><<<nblk, 512, LDS, st>>>(a);
     if (pl.slabs) reduce_224_kernel<false><<<dim3(56, T), 256, 0, st>>>(a, pl.S_A, pl.S_B);
   }
   return (int)hipGetLastError();
@@ -2336,19 +2414,30 @@ size_t gemm_tn_workspace_bytes(int Mmax, int N, int K) {
 }
 
 // dW[N,K] (fp32) (+)= dY[M,N]^T X[M,K]; contraction over M; split-K partials in `ws`.
+size_t gemm_tn_sumsq_slots(int N, int K) {
+  // GEMM blocks <= 16 pieces per 128 x 128 tile (the 256 x 224 tiles are larger), reduce blocks = one per 1024 elements
+  const size_t t128 = (size_t)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  return 32 * t128 + 64;
+}
+
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy,
-            int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background, bf16_t* img) {
+            int ldx, float* ws, size_t ws_bytes, hipStream_t st, int background, bf16_t* img, GradSink* sink) {
   if (check_dims(N, K, M, ldy, ldx, K) || (N & 7)) return -1;
+  if (sink) {
+    sink->used = 0;
+    if (sink->img_only && !img) return -1;
+  }
   if (const int orient = tn224_orient(M, N, K, background)) {
     const Plan224 pl = tn224_plan(M, N, K, orient, background ? T().tn224_bg_max_split : T().tn224_max_split);
     if ((size_t)pl.slabs * 256 * 224 * sizeof(float) > ws_bytes) return -3;
-    return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st, img);
+    return launch_tn224(dY, X, dW, accumulate, M, N, K, ldy, ldx, ws, orient, background, st, img, sink);
   }
   if (tn_bal_ok(M, N, K)) {
+    constexpr int LDS = 2 * STAGE_BYTES + 64;  // + the block-sum scratch of the GradSink epilogue
     static bool attr = false;
     if (!attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bal_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (e != hipSuccess) return (int)e;
       attr = true;
     }
@@ -2365,9 +2454,16 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
     a.wsA = ws;
     a.wsB = ws + (pl.S_A > 1 ? (size_t)pl.SA_act * N * K : 0);
     const int nblk = a.nA + pl.T_B * pl.SB_act;
-    gemm_tn_bal_kernel<<<nblk, 256, 2 * STAGE_BYTES, st>>>(a);
-    if (pl.S_A > 1 || pl.T_B > 0)
-      reduce_bal_kernel<<<dim3(16, a.tiles_r * a.tiles_c), 256, 0, st>>>(a, pl.SA_act, pl.SB_act);
+    const bool red = pl.S_A > 1 || pl.T_B > 0;
+    if (sink) {
+      sink->used = nblk + (red ? 16 * a.tiles_r * a.tiles_c : 0);
+      if (sink->sumsq && sink->used > sink->cap) return -3;
+      a.img_only = sink->img_only;
+      a.sumsq = sink->sumsq;
+      a.sumsq_red = sink->sumsq ? sink->sumsq + nblk : nullptr;
+    }
+    gemm_tn_bal_kernel<<<nblk, 256, LDS, st>>>(a);
+    if (red) reduce_bal_kernel<<<dim3(16, a.tiles_r * a.tiles_c), 256, 0, st>>>(a, pl.SA_act, pl.SB_act);
     return (int)hipGetLastError();
   }
   int splits = gemm_tn_splits(M, N, K);
@@ -2379,7 +2475,12 @@ int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M,
   int e = dma_ok ? launch<true, true, true, true>(a, splits, st) : launch<true, true, true, false>(a, splits, st);
   if (e) return e;
   size_t n = (size_t)N * K;
-  reduce_splits_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(ws, dW, n, splits, accumulate, img);
+  const unsigned rblk = (unsigned)((n / 4 + 255) / 256);
+  if (sink) {
+    sink->used = (int)rblk;
+    if (sink->sumsq && sink->used > sink->cap) return -3;
+  }
+  reduce_splits_kernel<<<rblk, 256, 0, st>>>(ws, dW, n, splits, accumulate, img, sink ? sink->img_only : 0, sink ? sink->sumsq : nullptr);
   return (int)hipGetLastError();
 }
 

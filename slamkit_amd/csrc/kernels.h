@@ -38,7 +38,7 @@ struct GemmTune {
 };
 GemmTune* gemm_default_tune();
 GemmTune* gemm_use_tune(GemmTune* t);  // install t (NULL = process default) for this thread; returns the previous one
-int gemm_tune_set(GemmTune* t, const char* key, long value);  // "gemm_*" option keys of slam_set_option; 1 = key known
+int gemm_tune_set(GemmTune* t, const char* key, long value);  // "gemm_*" option keys of slam_set_option; 1 = set, 0 = unknown key, -1 = out of range
 struct GemmTuneScope {
   GemmTune* old;
   explicit GemmTuneScope(GemmTune* t) : old(gemm_use_tune(t)) {}
@@ -55,6 +55,21 @@ int gemm_nt_dswiglu(const bf16_t* dY, const bf16_t* Wt, bf16_t* gu, int M, int N
 int gemm_nn(const bf16_t* dY, const bf16_t* W, bf16_t* dX, const bf16_t* resid, int M, int N, int K,
             hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);
+// How a launch delivers the FINAL values of a gradient tensor - the values the clip and the optimizer consume (round 6).
+// The last backward of an optimizer step may keep them in bf16 only, like the reference does (its parameters, hence its
+// gradients, are bf16: /root/reference config/model/slam.yaml:9), and emits the sum of squares of what it stored from the
+// same registers: no fp32 gradient store, no norm pass over the buffer.
+struct GradSink {
+  int img_only = 0;        // 1: final values are stored to the bf16 image ONLY (partial sums keep using dW / slabs in fp32)
+  float* sumsq = nullptr;  // one partial sum of squares per block, of the final values AS KEPT (the rounded ones when img_only),
+                           // added in a fixed order inside the block: block b of the GEMM kernel -> sumsq[b], block c
+                           // (y-major) of its reduce kernel -> sumsq[gemm blocks + c]. Blocks without a final store write
+                           // nothing: the caller clears the slots first.
+  int cap = 0;             // slots behind sumsq; a plan that needs more fails with -3
+  int used = 0;            // out: slots this launch owns
+};
+// upper bound of GradSink::used for dW[N][K] under every plan gemm_tn can choose
+size_t gemm_tn_sumsq_slots(int N, int K);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
 // background = 1: the launch shares the GPU with other streams (the engine's wgrad side stream): plans for CU-time per
 // flop instead of chip fill (no K-splitting on the 256 x 224 kernel)
@@ -62,7 +77,7 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K);
 // img (nullable): bf16 image of dW with the same indexing - every FINAL value of dW (unsplit tile epilogues, slab reduces) is
 // also stored there rounded to nearest even: the communication image of a bf16 gradient exchange, without a conversion pass
 int gemm_tn(const bf16_t* dY, const bf16_t* X, float* dW, int accumulate, int M, int N, int K, int ldy, int ldx,
-            float* ws, size_t ws_bytes, hipStream_t st, int background = 0, bf16_t* img = nullptr);
+            float* ws, size_t ws_bytes, hipStream_t st, int background = 0, bf16_t* img = nullptr, GradSink* sink = nullptr);
 
 // attention.hip
 // launch-shape choices of the backward kernels (engine-owned, "attn_jq" / "attn_kw" / "attn_nch" options):
@@ -87,7 +102,8 @@ int attn_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float*
 int rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int M, int H, float eps, hipStream_t st);
 int rmsnorm_bwd_blocks(int M);
 int rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img = nullptr);
+                bf16_t* dx, float* dw, int accumulate, float* part, int M, int H, hipStream_t st, bf16_t* dw_img = nullptr,
+                GradSink* sink = nullptr);
 int colsum_blocks(int M);
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, int accumulate, float* part, hipStream_t st);
 // csq / snq (nullable): the same tables times qscale - the QUERY heads are rotated with these, so that q is stored
@@ -114,24 +130,30 @@ int scale_rows_bf16(bf16_t* x, const float* coef, int M, int T, int ncols, hipSt
 // part: (n + grad_chunk_elems() - 1) / grad_chunk_elems() floats
 int grad_norm(const float* g, size_t n, float max_norm, float* part, float* out, hipStream_t st);
 int grad_chunk_elems();
-int grad_sumsq_chunks(const float* g, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st);
+int grad_sumsq_chunks(const void* g, int g_bf16, size_t n, size_t off, size_t cnt, float* chunk_sums, hipStream_t st);
 int grad_norm_from_chunks(const float* chunk_sums, size_t n_chunks, float max_norm, float* out, hipStream_t st);
-int adamw(float* p, bf16_t* pb, float* g, float* m, float* v, size_t n, const float* clip, double lr, double b1,
+// g_bf16 (here and below): the gradients at g are bf16_t (the last backward kept its final values in bf16 only), else float
+int adamw(float* p, bf16_t* pb, void* g, int g_bf16, float* m, float* v, size_t n, const float* clip, double lr, double b1,
           double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
 // bf16 parameters and bf16 moments updated in place (fp32 arithmetic per element, no master copy)
-int adamw_bf16(bf16_t* p, float* g, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
+int adamw_bf16(bf16_t* p, void* g, int g_bf16, bf16_t* m, bf16_t* v, size_t n, const float* clip, double lr, double b1, double b2,
                double eps, double wd, int step, int zero_grad, hipStream_t st);
 int f32_to_bf16(const float* s, bf16_t* d, size_t n, hipStream_t st);
+// the same conversion, emitting one GradSink partial (sum of squares of the rounded values) per 8192-element block
+int f32_to_bf16_sumsq_slots(size_t n);
+int f32_to_bf16_sumsq(const float* s, bf16_t* d, size_t n, float* sumsq, hipStream_t st);
 int bf16_to_f32(const bf16_t* s, float* d, size_t n, hipStream_t st);
 // AdamW over `batch` same-shaped [R][C] matrices (64-multiples) at a constant stride that ALSO writes the transposed bf16
 // image pt[C][R]; mode 0 = fp32 master + fp32 moments, 1 = fp32 master + bf16 moments, 2 = bf16 parameters + bf16 moments.
-int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, float* g, void* m, void* v, int R, int C, int batch, size_t batch_stride,
-                const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
+int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, void* g, int g_bf16, void* m, void* v, int R, int C, int batch,
+                size_t batch_stride, const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad,
+                hipStream_t st);
 // the same update on `batch` vectors of n elements at a constant stride (no transposed image)
-int adamw_strided(int mode, float* p, bf16_t* pb, float* g, void* m, void* v, size_t n, int batch, size_t stride, const float* clip,
-                  double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
+int adamw_strided(int mode, float* p, bf16_t* pb, void* g, int g_bf16, void* m, void* v, size_t n, int batch, size_t stride,
+                  const float* clip, double lr, double b1, double b2, double eps, double wd, int step, int zero_grad, hipStream_t st);
 int transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, int batch, size_t batch_stride, hipStream_t st);
 int colsum_finish_many(const float* part, size_t part_stride, int nb, int N, float* out, size_t out_stride, int count,
-                       int accumulate, hipStream_t st, bf16_t* img = nullptr);  // img: bf16 image of `out` (same indexing), nullable
+                       int accumulate, hipStream_t st, bf16_t* img = nullptr,  // img: bf16 image of `out` (same indexing), nullable
+                       GradSink* sink = nullptr);
 
 }  // namespace slam

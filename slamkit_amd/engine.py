@@ -227,7 +227,11 @@ class Engine:
                                        stream if stream is not None else current_stream_ptr()))
 
     def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0,
-                 bucket_cb: Optional[Callable[[int, int], None]] = None, stream: Optional[int] = None):
+                 bucket_cb: Optional[Callable[[int, int], None]] = None, stream: Optional[int] = None, final: int = 0):
+        """final (option "grad_final_next"): 1 = last backward of its optimizer step (the final-value stores emit the
+        gradient-norm partials), 2 = the same with the final values kept in bf16 only, in the set_grad_image buffer."""
+        if final:
+            self.set_option("grad_final_next", int(final))
         if bucket_cb is None:
             cb = C.cast(None, BUCKET_CB)
         else:

@@ -214,7 +214,9 @@ class UnitLM(TokenLM):
             self._ensure_workspace(config.max_tokens)
             self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
-        for opt in ("fuse_swiglu", "fuse_dswiglu", "gemm_group_rows", "gemm_glds", "gemm_tn_splits", "gemm_tn_balanced", "gemm_nt_store", "gemm_256", "gemm_nt224", "gemm_nt224_min_k", "gemm_256_dswiglu", "gemm_256_persist", "gemm_256_stagger", "gemm_256_stagger_dswiglu", "gemm_256_cohorts", "gemm_256_persist_cus", "gemm_group_cols_256", "gemm_group_rows_256", "gemm_mf32", "gemm_256_w4", "gemm_tn224", "gemm_tn224_min_m", "gemm_tn224_max_split", "gemm_tn_bal_bg_max_split", "gemm_tn224_bg_min_m", "gemm_tn224_bg_max_split", "bwd_wgrad_stream", "bwd_wgrad_cus", "attn_jq", "attn_kw", "attn_nch", "attn_prio", "fuse_adamw_t"):  # tuning overrides, e.g. SLAM_FUSE_SWIGLU=0
+            self.flat_grads16 = None       # bf16 gradients of the step's last backward (enable_bf16_grads)
+            self._grads_in_bf16 = False    # the last backward left its final values there, not in flat_grads
+        for opt in ("fuse_swiglu", "fuse_dswiglu", "gemm_group_rows", "gemm_glds", "gemm_tn_splits", "gemm_tn_balanced", "gemm_256", "gemm_nt224", "gemm_nt224_min_k", "gemm_256_dswiglu", "gemm_256_persist", "gemm_256_stagger", "gemm_256_stagger_dswiglu", "gemm_256_cohorts", "gemm_256_persist_cus", "gemm_group_cols_256", "gemm_group_rows_256", "gemm_mf32", "gemm_256_w4", "gemm_tn224", "gemm_tn224_min_m", "gemm_tn224_max_split", "gemm_tn_bal_bg_max_split", "gemm_tn224_bg_min_m", "gemm_tn224_bg_max_split", "bwd_wgrad_stream", "bwd_wgrad_cus", "attn_jq", "attn_kw", "attn_nch", "attn_prio", "fuse_adamw_t"):  # tuning overrides, e.g. SLAM_FUSE_SWIGLU=0
             v = os.environ.get("SLAM_" + opt.upper())
             if v is not None:
                 self.engine.set_option(opt, int(v))
@@ -330,9 +332,21 @@ class UnitLM(TokenLM):
             yield v
 
     def named_grads(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        """(name, gradient) of the last backward: views of the fp32 buffer, or - when that backward kept its final values in
+        bf16 only (`backward(final=2)`: the reference's own gradient precision) - fp32 copies of the bf16 buffer's windows."""
         self.engine.join()
         for k in self.key_map:
-            yield k, self._view(self.flat_grads, k)
+            if self._grads_in_bf16:
+                yield k, self._view(self.flat_grads16, k).float()
+            else:
+                yield k, self._view(self.flat_grads, k)
+
+    def enable_bf16_grads(self):
+        """Allocate the bf16 gradient buffer `backward(final=2)` stores the step's final gradient values in."""
+        if self.flat_grads16 is None:
+            with torch.cuda.device(self.device):
+                self.flat_grads16 = torch.zeros(self.engine.n_params, dtype=torch.bfloat16, device=self.device)
+        return self.flat_grads16
 
     def num_parameters(self) -> int:
         return sum(v.numel() for v in self.parameters())
@@ -483,9 +497,14 @@ class UnitLM(TokenLM):
 
     __call__ = forward
 
-    def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0, bucket_cb=None):
-        """d(loss * grad_scale)/dparams accumulated into `flat_grads` (fp32)."""
-        self.engine.backward(grad_scale, bucket_layers, bucket_cb)
+    def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0, bucket_cb=None, final: int = 0):
+        """d(loss * grad_scale)/dparams accumulated into `flat_grads` (fp32). final = 1 | 2 marks the last backward of an
+        optimizer step (engine option "grad_final_next"): the gradient-norm partials come out of the final-value stores, and
+        with 2 the final values are kept in bf16 only (`flat_grads16`; `named_grads` reads them there)."""
+        if final == 2:
+            self.engine.set_grad_image(self.enable_bf16_grads())
+        self.engine.backward(grad_scale, bucket_layers, bucket_cb, final=final)
+        self._grads_in_bf16 = final == 2
 
     def zero_grad(self):
         self.engine.zero_grads()
@@ -537,6 +556,7 @@ class UnitLM(TokenLM):
         self._hold = self._hold + (coef,)
         self.engine.scale_loss_rows(coef, B, T)
         self.engine.backward(grad_scale, kw.get("bucket_layers", 0), kw.get("bucket_cb"))
+        self._grads_in_bf16 = False
 
     @torch.no_grad()
     def generate(self, inputs: Optional[torch.Tensor] = None, generation_config=None, max_new_tokens: int = 32,

@@ -59,6 +59,12 @@ class SLAMTrainer:
                 model.drop_master()  # the bf16 parameters become the only copy (the recipe's torch_dtype: bfloat16)
         if self.moment_dtype == torch.bfloat16 and self.state_dtype == torch.float32 and getattr(self.args, "overlap_optimizer", False):
             raise ValueError("overlap_optimizer is implemented for the fp32-state optimizer only")
+        gd = getattr(self.args, "grad_dtype", None) or ("bfloat16" if osd == "bfloat16" else "float32")
+        if gd not in ("float32", "bfloat16"):
+            raise ValueError(f"grad_dtype must be float32 or bfloat16, got {gd!r}")
+        # how the last backward of a step delivers its final values (UnitLM.backward(final=)): 2 = bf16 only, 1 = fp32; both
+        # emit the gradient-norm partials from the final-value stores. Models without the hook (CPU stubs of the gloo tests): 0
+        self._final_mode = (2 if gd == "bfloat16" else 1) if hasattr(model, "enable_bf16_grads") else 0
         self.exp_avg = torch.zeros(n, dtype=self.moment_dtype, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=self.moment_dtype, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -113,6 +119,8 @@ class SLAMTrainer:
         if last_micro and (self.world > 1 or self.reducer.force):
             self.reducer.arm_image()  # bf16 exchange: this backward writes the communication image itself (no pack pass)
             model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
+        elif last_micro and self._final_mode:
+            model.backward(grad_scale, final=self._final_mode)  # norm partials (and bf16-only final values) from this backward
         else:
             model.backward(grad_scale)
         return loss

@@ -233,6 +233,18 @@ args = SLAMTrainingArguments(per_device_train_batch_size=2, gradient_accumulatio
                              optim_state_dtype=os.environ.get("OSD") or "float32")
 tr = SLAMTrainer(model=m, args=args)
 init = (m.flat_master if m.flat_master is not None else m.flat_params).float().cpu().clone()
+sd_bf = {k: v.float() for k, v in m.state_dict(torch.bfloat16).items()}   # the weights the engine computes with, HF names
+snap = {}
+if os.environ.get("SNAP") == "1":   # the exchanged, pre-clip gradients and the loss of optimizer step 1 (for the oracle check)
+    _upd = tr._update
+    def _snap_update(lr, zero_grad):
+        if not snap:
+            torch.cuda.synchronize()
+            gsrc = m.flat_grads.clone()
+            snap["grads"] = {k: m._view(gsrc, k).cpu().clone() for k in m.key_map}
+            snap["loss_local"] = float(tr._loss_acc)
+        return _upd(lr, zero_grad)
+    tr._update = _snap_update
 g = torch.Generator().manual_seed(0)
 batches = []
 per_step = 2 * int(os.environ.get("MB", "1"))   # micro-batches per optimizer step over all ranks (MB per rank at world 2)
@@ -250,7 +262,8 @@ tr._gather_optimizer_state()
 torch.cuda.synchronize()
 torch.save({"master": (m.flat_master if m.flat_master is not None else m.flat_params).cpu(), "params": m.flat_params.cpu(),
             "exp_avg": tr.exp_avg.cpu(), "owned": list(getattr(tr.reducer, "owned", []) or []), "seen": tr.state.num_input_tokens_seen,
-            "init": init, "grad_norm": float(tr.norm_out[0])},
+            "init": init, "grad_norm": float(tr.norm_out[0]), "sd_bf": sd_bf, "snap": snap,
+            "step1": [{k: v.clone() for k, v in b.items()} for b in batches[:per_step]]},
            os.environ["OUT"] + f".{rank}")
 if world > 1:
     dist.barrier()
@@ -274,6 +287,44 @@ def _run_world(tmp_path, name, world, **env):
     return [torch.load(out + f".{r}") for r in range(world)]
 
 
+def _check_step1_against_oracle(r0, r1, comm):
+    """T10 against the ORACLE (round-5 verdict: the world-2 runs were only ever compared with the engine itself, so a scale
+    error common to both engine paths - the global num_items divisor, `loss *= world` - would have passed): optimizer step 1 of
+    the two-rank run restated on the CPU following /root/reference slamkit/trainer/slam_trainer.py:67-71 + HF Trainer
+    (transformers/trainer.py num_items_in_batch gathered over ranks and micro-batches; DDP sums what each rank computed from
+    ITS micro-batch with the GLOBAL count as divisor) - O.forward_loss_grads on each rank's micro-batch with the global
+    `num_items_in_batch`, gradients and losses summed. The engine's exchanged, pre-clip gradient buffer (all_reduce: complete on
+    every rank) must have that global norm (2e-3), direction per tensor (cosine >= 0.999; >= 0.99 for the norm / bias vectors,
+    the suite's bar for them) and the ranks' losses must add up to the oracle's loss (2e-2)."""
+    import torch
+    from oracle import slam_oracle as O
+    from tests.gpu_util import cosine
+    cfg = O.OracleConfig(**{**O.TINY.to_dict(), "n_layers": 4})   # W2_WORKER's model
+    micro = r0["step1"]
+    assert len(micro) == 2 and torch.equal(micro[0]["input_ids"], r1["step1"][0]["input_ids"])
+    n_glob = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))   # unshifted count over BOTH ranks (trainer.py:2141-2201)
+    tot, loss = None, 0.0
+    for mb in micro:   # rank r ran micro[r]
+        l, _, g = O.forward_loss_grads(cfg, r0["sd_bf"], mb["input_ids"], mb["labels"], num_items_in_batch=n_glob)
+        loss += float(l)
+        tot = g if tot is None else {k: tot[k] + g[k] for k in g}
+    for r in (r0, r1):
+        eg = r["snap"]["grads"]
+        assert set(eg) == set(tot)
+        n_e = float(torch.cat([v.flatten().double() for v in eg.values()]).norm())
+        n_o = float(torch.cat([tot[k].flatten().double() for k in eg]).norm())
+        worst = min((cosine(eg[k], tot[k]), k) for k in eg if tot[k].dim() == 2)
+        worst_v = min((cosine(eg[k], tot[k]), k) for k in eg if tot[k].dim() == 1)
+        assert abs(n_e - n_o) <= 2e-3 * n_o, (comm, n_e, n_o)
+        assert worst[0] >= 0.999, (comm, worst)
+        assert worst_v[0] >= 0.99, (comm, worst_v)
+    loss_e = r0["snap"]["loss_local"] + r1["snap"]["loss_local"]
+    print(f"[parity] world 2 step 1 vs ORACLE ({comm} wire): global grad norm engine {n_e:.6f} oracle {n_o:.6f}, worst matrix cosine "
+          f"{worst[0]:.6f} ({worst[1]}), worst vector cosine {worst_v[0]:.5f}, loss engine {loss_e:.5f} oracle {loss:.5f}")
+    assert abs(loss_e - loss) <= 2e-2, (loss_e, loss)
+    assert torch.equal(r0["snap"]["grads"]["lm.model.norm.weight"], r1["snap"]["grads"]["lm.model.norm.weight"])
+
+
 @pytest.mark.parametrize("osd", ["float32", "bfloat16"])
 def test_two_ranks_on_one_gpu_real_engine_sharded_equals_replicated(tmp_path, osd):
     """WORLD SIZE 2 with the REAL engine: two processes share the one GPU and exchange over gloo (the buckets travel through
@@ -289,7 +340,9 @@ def test_two_ranks_on_one_gpu_real_engine_sharded_equals_replicated(tmp_path, os
     res = {}
     for comm in ("float32", "bfloat16"):
         for algo in ("all_reduce", "rs_ag"):
-            r0, r1 = _run_world(tmp_path, f"{comm}_{algo}", 2, COMM=comm, ALGO=algo, OSD=osd)
+            r0, r1 = _run_world(tmp_path, f"{comm}_{algo}", 2, COMM=comm, ALGO=algo, OSD=osd, SNAP="1")
+            if algo == "all_reduce":
+                _check_step1_against_oracle(r0, r1, comm)
             for k in ("master", "params", "exp_avg"):
                 assert torch.equal(r0[k], r1[k]), (comm, algo, k, "ranks differ")
             res[(comm, algo)] = r0

@@ -4,7 +4,9 @@ that is almost only epilogue). HIP events, interleaved, random operands. Usage: 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slamkit_amd import engine as E
-lib = E.load_library(); st = E.current_stream_ptr(); dev = "cuda"
+# the no-store switch exists only in the -DSLAM_PROBES build (python -m slamkit_amd.csrc.build --probes); the product library rejects it
+from slamkit_amd.csrc import build as _B
+lib = E.load_library(_B.build(verbose=False, probes=True)); st = E.current_stream_ptr(); dev = "cuda"
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 def rb(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 def timeit(fn):

@@ -3,7 +3,9 @@ pass: cycles vs wall -> do the stores cost cycles (stall) or clock (power)? Summ
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slamkit_amd import engine as E
-lib = E.load_library(); st = E.current_stream_ptr(); dev = "cuda"
+# the no-store switch exists only in the -DSLAM_PROBES build (python -m slamkit_amd.csrc.build --probes); the product library rejects it
+from slamkit_amd.csrc import build as _B
+lib = E.load_library(_B.build(verbose=False, probes=True)); st = E.current_stream_ptr(); dev = "cuda"
 def rb(*s): return torch.randn(*s, device=dev).to(torch.bfloat16)
 manifest = []
 for name, kind, M, N, K in [("gate|up + SwiGLU", "swiglu", 8192, 9728, 896), ("gate|up plain", "plain", 8192, 9728, 896), ("down dgrad + dSwiGLU", "dswiglu", 8192, 4864, 896)]:
