@@ -119,6 +119,17 @@ int slam_comm_init(SlamEngine* h, const void* id, int32_t rank, int32_t world);
 int slam_comm_destroy(SlamEngine* h);
 int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int32_t bf16_exchange, slam_stream_t ready);
 int slam_comm_finish(SlamEngine* h, slam_stream_t stream);
+/* The reduce-scatter / all-gather form of the same exchange (what slamkit_amd's trainer runs as ddp_algo = "rs_ag"; SURVEY.md
+ * §5 comm row, §8e): per bucket the ranks reduce-scatter the gradients - rank r ends up with the summed shard
+ * [offset + r s, offset + (r + 1) s), s = count / world (count = world x a multiple of 8) - the optimizer runs on the owned shards
+ * (slam_grad_sumsq_chunks + one all-reduce of the chunk sums, slam_adamw_range*), and the updated bf16 PARAMETERS are all-gathered:
+ *   callback: slam_reduce_scatter_grads_async(h, offset, count, bf16, ready)      -> slam_comm_finish(h, stream)
+ *   update of the owned shards on `stream`, then per bucket, lowest offsets first:
+ *             slam_allgather_params_async(h, offset, count, stream)
+ * The gather runs on the communication stream under the next forward, which waits for each bucket right before its first read
+ * (the engine registers the wait itself - slam_add_param_wait is for consumers with their own communicator). */
+int slam_reduce_scatter_grads_async(SlamEngine* h, int64_t offset, int64_t count, int32_t bf16_exchange, slam_stream_t ready);
+int slam_allgather_params_async(SlamEngine* h, int64_t offset, int64_t count, slam_stream_t ready);
 /* Valid inside a slam_bucket_cb call: the stream on which the reported range is complete - the consumer records its
  * "bucket ready" event THERE. NULL = the stream passed to slam_backward. With the weight-gradient stream on, the
  * intermediate buckets are complete on that engine-owned stream (which has also been ordered after the norm / bias

@@ -12,7 +12,18 @@
 #include <utility>
 #include <vector>
 
-#include <rccl/rccl.h>  // types only: the library is looked up at run time (slam_comm_*)
+// RCCL: types only - the library is looked up at run time (slam_comm_*). A box without the RCCL headers still builds the engine
+// (the handful of declarations below follow rccl.h / nccl.h; their values are part of the library's stable ABI).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7,
+               ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include "../../include/slam_engine.h"
 #include "kernels.h"
@@ -95,6 +106,10 @@ struct SlamEngine {
   AttnTune attn_tune = attn_default_tune();
   GemmTune gemm_tune = *gemm_default_tune();
   int wgrad_stream = 1;  // measured +3.6 % step throughput on Slam-358M (282.2k -> 292.3k tok/s, same box)
+  // "bwd_aux_side" (round 6): the launches of backward that nothing on the dgrad chain reads - the bias column sums of d(qkv)
+  // and the norm / bias finish kernels - go to the weight-gradient stream as well: the caller's stream IS the critical path
+  // (every kernel on it feeds the next), the weight-gradient stream has ~230 us of slack per layer
+  int aux_side = 1;
   hipStream_t wside = nullptr;
   // "bwd_wgrad_cus" > 0: the wgrad stream is created with a CU mask of that many CUs (the low bits of the mask: on gfx950
   // bit i is XCD i % 8, shader engine (i / 8) % 4, CU i / 32 - a prefix of 32 k bits is k CUs in every shader engine of every
@@ -113,7 +128,9 @@ struct SlamEngine {
   hipStream_t bucket_stream = nullptr;  // see slam_bucket_stream
   // engine-side gradient exchange (slam_comm_*): one RCCL communicator, one communication stream, an event pool
   void* comm = nullptr;                 // ncclComm_t
-  int comm_world = 0;
+  int comm_world = 0, comm_rank = 0;
+  std::vector<hipEvent_t> ag_ev;        // "parameters of this bucket have arrived" (slam_allgather_params_async -> the next forward)
+  size_t ag_ev_used = 0;
   hipStream_t comm_stream = nullptr;
   std::vector<hipEvent_t> comm_ev;
   size_t comm_ev_used = 0;
@@ -130,6 +147,7 @@ struct SlamEngine {
     for (hipEvent_t e : pw_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : tg_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : comm_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ag_ev) (void)hipEventDestroy(e);
     if (comm_stream) { (void)hipStreamSynchronize(comm_stream); (void)hipStreamDestroy(comm_stream); }
   }
   // parameter ranges another stream is still writing (sharded optimizer: the bf16 parameter all-gather on the
@@ -603,6 +621,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   }
   if (!strcmp(key, "overlap_adamw") && h) { h->overlap_adamw = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_stream") && h) { h->wgrad_stream = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "bwd_aux_side") && h) { h->aux_side = value != 0; return SLAM_OK; }
   if (!strcmp(key, "bwd_wgrad_cus") && h) { h->wside_cus = (int)value; return SLAM_OK; }
   if (!strcmp(key, "time_param_waits") && h) { h->time_param_waits = value != 0; return SLAM_OK; }
   if (!strcmp(key, "time_gateup") && h) {
@@ -722,6 +741,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   CK(join_params(h, st));
+  h->ag_ev_used = 0;  // every parameter arrival has been waited for: the pool is free for the next step's gathers
   if (h->params_t_dirty) CK(slam_refresh_transposed(h, stream));
   const int M = h->B * h->T;
   const int H = d.hidden, I = d.intermediate, L = d.n_layers, nH = d.n_heads, nKV = d.n_kv_heads;
@@ -802,10 +822,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     return (int)hipStreamWaitEvent(to, e, 0);
   };
   auto fork = [&]() -> int { return two ? edge(st, ws) : 0; };
+  const bool aux = two && h->aux_side != 0;
   // dW (+)= a^T b on a weight-gradient stream
   // is_final: the launch stores the tensor's final values (everything but the head's half of the tied embedding gradient)
-  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k, bf16_t* gi, bool is_final = true) -> int {
-    if (int r = fork()) return r;
+  auto wgrad = [&](int fam, const bf16_t* a, const bf16_t* b, float* g, int n, int k, bf16_t* gi, bool is_final = true,
+                   bool handed_over = false) -> int {  // handed_over: ws already waits for everything enqueued on st so far
+    if (!handed_over)
+      if (int r = fork()) return r;
     const int slot = fam_begin(h, fam, ws);
     const int r = take(gemm_tn(a, b, g, acc, M, n, k, n, k, h->gemm_ws, h->gemm_ws_bytes, ws, two ? 1 : 0, gi, is_final ? sink() : nullptr));
     fam_end(h, slot, ws);
@@ -845,8 +868,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
     TK(F_O_DGRAD, st, dgrad(dh2, o.wo, h->d_o, H, HD));
     TK(F_ATTN_BWD, st, attn_bwd(a.qkv, a.o, h->d_o, a.lse, h->dsum, h->nlse, dqkv, h->dkv_part, h->cur_seg_s, h->cur_seg_e, h->attn_plan_buf, h->attn_tune, h->cosb, h->sinb,
                 M, nH, nKV, d.head_dim, st));  // dq / dk come out already rotated back
-    CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
-    CK(wgrad(F_WQKV_WGRAD, dqkv, a.x1, G + o.wqkv, h->QKV, H, img(o.wqkv)));
+    if (aux) {  // behind the same hand-over as the Wqkv gradient: both read d(qkv)
+      CK(fork());
+      CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, ws));
+    } else {
+      CK(colsum_bf16(dqkv, h->QKV, M, h->QKV, nullptr, 1, h->bias_part + (size_t)l * h->bias_ps, st));
+    }
+    CK(wgrad(F_WQKV_WGRAD, dqkv, a.x1, G + o.wqkv, h->QKV, H, img(o.wqkv), true, aux));
     TK(F_QKV_DGRAD, st, dgrad(dqkv, o.wqkv, h->dx, h->QKV, H));
     dh = a.hmid;  // grad wrt hs[l]: hmid[l] was last read by the ln2 backward above
     TK(F_NORM_BWD, st, rmsnorm_bwd(h->dx, h->hs[l], P + o.ln1, a.rstd1, dh2, dh, nullptr, 1, h->ln_part + (size_t)(2 * l) * h->ln_ps, M, H, st));
@@ -857,15 +885,17 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       // the layers [l, fin_hi) are complete: finish their norm / bias partial slabs in three launches
       const int cnt = fin_hi - l;
       const int nbl = rmsnorm_bwd_blocks(M), nbc = colsum_blocks(M);
-      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, st, img(o.ln1), sink())));
-      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, st, img(o.ln2), sink())));
-      CK(take(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, st, img(o.bqkv), sink())));
+      hipStream_t fs = aux ? ws : st;  // aux: after the norm backward above (the hand-over) and the column sums already on ws
+      if (aux) CK(fork());
+      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln1, (size_t)h->layer_stride, cnt, acc, fs, img(o.ln1), sink())));
+      CK(take(colsum_finish_many(h->ln_part + (size_t)(2 * l + 1) * h->ln_ps, 2 * h->ln_ps, nbl, H, G + o.ln2, (size_t)h->layer_stride, cnt, acc, fs, img(o.ln2), sink())));
+      CK(take(colsum_finish_many(h->bias_part + (size_t)l * h->bias_ps, h->bias_ps, nbc, h->QKV, G + o.bqkv, (size_t)h->layer_stride, cnt, acc, fs, img(o.bqkv), sink())));
       fin_hi = l;
     }
     if (boundary) {
       // the side stream is in order: its last launch of layer l covers every wgrad of the range. Order it after the
       // finish kernels above as well and hand IT to the consumer (slam_bucket_stream): main does not stall here.
-      CK(fork());
+      if (!aux) CK(fork());  // aux: the finish kernels ARE on the side stream, behind a hand-over of their own
       h->bucket_stream = two ? ws : nullptr;
       cb(user, o.ln1, bucket_end - o.ln1);
       h->bucket_stream = nullptr;
@@ -1157,33 +1187,39 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+// resolved ONCE, by whichever thread gets here first (function-local static: C++11 guarantees the others wait - a
+// single-process multi-GPU consumer calls slam_comm_init from one thread per rank at the same time, ncclCommInitRank blocks
+// until all have joined)
+const Rccl* rccl() {
+  static const Rccl r = [] {
+    Rccl t;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.lib) break;
+      t.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (t.lib) break;
     }
-    if (r.lib) {
-      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
-      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.lib = nullptr;
+    if (t.lib) {
+      t.GetUniqueId = (decltype(t.GetUniqueId))dlsym(t.lib, "ncclGetUniqueId");
+      t.CommInitRank = (decltype(t.CommInitRank))dlsym(t.lib, "ncclCommInitRank");
+      t.CommDestroy = (decltype(t.CommDestroy))dlsym(t.lib, "ncclCommDestroy");
+      t.AllReduce = (decltype(t.AllReduce))dlsym(t.lib, "ncclAllReduce");
+      t.ReduceScatter = (decltype(t.ReduceScatter))dlsym(t.lib, "ncclReduceScatter");
+      t.AllGather = (decltype(t.AllGather))dlsym(t.lib, "ncclAllGather");
+      t.GetErrorString = (decltype(t.GetErrorString))dlsym(t.lib, "ncclGetErrorString");
+      if (!t.GetUniqueId || !t.CommInitRank || !t.CommDestroy || !t.AllReduce || !t.ReduceScatter || !t.AllGather) t.lib = nullptr;
     }
-  }
+    return t;
+  }();
   return r.lib ? &r : nullptr;
 }
 }  // namespace
 
 int slam_comm_unique_id(void* id_out, int32_t bytes) {
   if (!id_out || bytes < (int32_t)sizeof(ncclUniqueId)) return SLAM_EINVAL;
-  Rccl* r = rccl();
+  const Rccl* r = rccl();
   if (!r) return SLAM_EUNSUPPORTED;
   ncclUniqueId id;
   if (r->GetUniqueId(&id) != ncclSuccess) return SLAM_ESTATE;
@@ -1194,16 +1230,17 @@ int slam_comm_unique_id(void* id_out, int32_t bytes) {
 int slam_comm_init(SlamEngine* h, const void* id, int32_t rank, int32_t world) {
   if (!h || !id || world <= 0 || rank < 0 || rank >= world) return SLAM_EINVAL;
   if (h->comm) return h->fail(SLAM_ESTATE, "communicator already initialised");
-  Rccl* r = rccl();
+  const Rccl* r = rccl();
   if (!r) return h->fail(SLAM_EUNSUPPORTED, "librccl.so.1 not found");
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
+  if (!h->comm_stream) CK((int)hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));  // before the communicator: nothing to undo on failure
   ncclComm_t c = nullptr;
   const ncclResult_t e = r->CommInitRank(&c, world, uid, rank);
   if (e != ncclSuccess) return h->fail(SLAM_ESTATE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
-  if (!h->comm_stream) CK((int)hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   h->comm = c;
   h->comm_world = world;
+  h->comm_rank = rank;
   return SLAM_OK;
 }
 
@@ -1211,7 +1248,7 @@ int slam_comm_destroy(SlamEngine* h) {
   if (!h) return SLAM_EINVAL;
   if (h->comm) {
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    Rccl* r = rccl();
+    const Rccl* r = rccl();
     if (r) (void)r->CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr;
     h->comm_world = 0;
@@ -1226,11 +1263,11 @@ int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int
   if (bf16_exchange && (!h->last_grad_img || (offset & 3) || (count & 3)))
     return h->fail(SLAM_ESTATE, "bf16 exchange: bind an image with slam_set_grad_image before the backward (ranges in multiples of 4)");
   if (!count) return SLAM_OK;
-  Rccl* r = rccl();
+  const Rccl* r = rccl();
   // communication stream behind the producers of the range
   if (h->comm_ev_used == h->comm_ev.size()) {
     hipEvent_t e;
-    CK((int)hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    CK((int)hipEventCreateWithFlags(&e, sync_event_flags()));  // SLAM_EVENT_SYSTEM_FENCE=1 covers the path whose data leaves the device
     h->comm_ev.push_back(e);
   }
   hipEvent_t ev = h->comm_ev[h->comm_ev_used++];
@@ -1248,12 +1285,75 @@ int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int
   return SLAM_OK;
 }
 
+// ---- the reduce-scatter / all-gather form of the exchange (what the Python trainer runs as ddp_algo = "rs_ag"; SURVEY.md §5
+// comm row, §8e: every one of a GPU's 7 xGMI links carries one shard concurrently) for the torch-free consumer -------------------
+static int comm_behind(SlamEngine* h, hipStream_t ready) {  // the communication stream continues after everything on `ready`
+  if (h->comm_ev_used == h->comm_ev.size()) {
+    hipEvent_t e;
+    CK((int)hipEventCreateWithFlags(&e, sync_event_flags()));
+    h->comm_ev.push_back(e);
+  }
+  hipEvent_t ev = h->comm_ev[h->comm_ev_used++];
+  CK((int)hipEventRecord(ev, ready));
+  CK((int)hipStreamWaitEvent(h->comm_stream, ev, 0));
+  return SLAM_OK;
+}
+
+int slam_reduce_scatter_grads_async(SlamEngine* h, int64_t offset, int64_t count, int32_t bf16_exchange, slam_stream_t ready) {
+  if (!h || offset < 0 || count < 0 || offset + count > h->n_params) return SLAM_EINVAL;
+  if (!h->comm) return h->fail(SLAM_ESTATE, "slam_comm_init first");
+  if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
+  const int64_t w = h->comm_world, s = count / w;
+  if (count % w || (s & 7) || (offset & 7)) return h->fail(SLAM_EINVAL, "reduce-scatter: count must be world x a multiple of 8 elements, offset a multiple of 8");
+  if (bf16_exchange && !h->last_grad_img) return h->fail(SLAM_ESTATE, "bf16 exchange: bind an image with slam_set_grad_image before the backward");
+  if (!count) return SLAM_OK;
+  const Rccl* r = rccl();
+  if (int rc = comm_behind(h, (hipStream_t)ready)) return rc;
+  const int64_t mine = offset + (int64_t)h->comm_rank * s;
+  ncclResult_t e;
+  if (bf16_exchange) {
+    bf16_t* img = h->last_grad_img;
+    e = r->ReduceScatter(img + offset, img + mine, (size_t)s, ncclBfloat16, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
+    // gradients kept in bf16 only (grad_final_next = 2): the reduced shard is read where it is; else widen it into the fp32 buffer
+    if (e == ncclSuccess && h->gfinal != 2) CK(bf16_to_f32(img + mine, h->grads + mine, (size_t)s, h->comm_stream));
+  } else {
+    e = r->ReduceScatter(h->grads + offset, h->grads + mine, (size_t)s, ncclFloat32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
+  }
+  if (e != ncclSuccess) return h->fail(SLAM_ESTATE, r->GetErrorString ? r->GetErrorString(e) : "ncclReduceScatter failed");
+  return SLAM_OK;
+}
+
+int slam_allgather_params_async(SlamEngine* h, int64_t offset, int64_t count, slam_stream_t ready) {
+  if (!h || offset < 0 || count < 0 || offset + count > h->n_params) return SLAM_EINVAL;
+  if (!h->comm) return h->fail(SLAM_ESTATE, "slam_comm_init first");
+  if (!h->params) return h->fail(SLAM_ESTATE, "bind params first");
+  const int64_t w = h->comm_world, s = count / w;
+  if (count % w || (s & 7) || (offset & 7)) return h->fail(SLAM_EINVAL, "all-gather: count must be world x a multiple of 8 elements, offset a multiple of 8");
+  if (!count) return SLAM_OK;
+  const Rccl* r = rccl();
+  if (int rc = comm_behind(h, (hipStream_t)ready)) return rc;
+  bf16_t* P = h->params;
+  const ncclResult_t e = r->AllGather(P + offset + (int64_t)h->comm_rank * s, P + offset, (size_t)s, ncclBfloat16, (ncclComm_t)h->comm, h->comm_stream);
+  if (e != ncclSuccess) return h->fail(SLAM_ESTATE, r->GetErrorString ? r->GetErrorString(e) : "ncclAllGather failed");
+  // the next reader of the range (slam_forward, layer by layer) waits for the arrival right before its first read
+  if (h->ag_ev_used == h->ag_ev.size()) {
+    hipEvent_t ev;
+    CK((int)hipEventCreateWithFlags(&ev, sync_event_flags()));
+    h->ag_ev.push_back(ev);
+  }
+  hipEvent_t ev = h->ag_ev[h->ag_ev_used++];
+  CK((int)hipEventRecord(ev, h->comm_stream));
+  h->pwaits.push_back({offset, offset + count, ev});
+  h->params_t_dirty = h->params_t != nullptr;
+  return SLAM_OK;
+}
+
 int slam_comm_finish(SlamEngine* h, slam_stream_t stream) {
   if (!h) return SLAM_EINVAL;
   if (!h->comm_stream || !h->comm_ev_used) return SLAM_OK;
   if (h->comm_ev_used == h->comm_ev.size()) {
     hipEvent_t e;
-    CK((int)hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    CK((int)hipEventCreateWithFlags(&e, sync_event_flags()));  // SLAM_EVENT_SYSTEM_FENCE=1 covers the path whose data leaves the device
     h->comm_ev.push_back(e);
   }
   hipEvent_t ev = h->comm_ev[h->comm_ev_used];

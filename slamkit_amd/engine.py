@@ -91,6 +91,8 @@ def load_library(path: Optional[str] = None):
         "slam_comm_destroy": (C.c_int, [vp]),
         "slam_allreduce_grads_async": (C.c_int, [vp, i64, i64, C.c_int32, vp]),
         "slam_comm_finish": (C.c_int, [vp, vp]),
+        "slam_reduce_scatter_grads_async": (C.c_int, [vp, i64, i64, C.c_int32, vp]),
+        "slam_allgather_params_async": (C.c_int, [vp, i64, i64, vp]),
         "slam_gateup_launch_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int32]),
         "slam_family_ms": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
         "slam_family_name": (C.c_char_p, [C.c_int32]),
@@ -388,6 +390,17 @@ class Engine:
         enqueued so far on `ready_stream` (raw handle; None = torch's current stream)."""
         self._ck(self.lib.slam_allreduce_grads_async(self.h, int(offset), int(count), int(bool(bf16_exchange)),
                                                      ready_stream if ready_stream else current_stream_ptr()))
+
+    def reduce_scatter_grads_async(self, offset: int, count: int, bf16_exchange: bool = False, ready_stream=None):
+        """Reduce-scatter grads[offset:offset+count] over the communicator: this rank ends up with the summed shard
+        [offset + rank * count / world, ...) (engine communication stream, behind `ready_stream`)."""
+        self._ck(self.lib.slam_reduce_scatter_grads_async(self.h, int(offset), int(count), int(bool(bf16_exchange)),
+                                                          ready_stream if ready_stream else current_stream_ptr()))
+
+    def allgather_params_async(self, offset: int, count: int, ready_stream=None):
+        """All-gather the bf16 parameters of the bucket from their owners; the next forward waits per bucket."""
+        self._ck(self.lib.slam_allgather_params_async(self.h, int(offset), int(count),
+                                                      ready_stream if ready_stream else current_stream_ptr()))
 
     def comm_finish(self, stream=None):
         self._ck(self.lib.slam_comm_finish(self.h, stream if stream is not None else current_stream_ptr()))

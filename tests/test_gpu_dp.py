@@ -393,9 +393,10 @@ g = torch.Generator().manual_seed(0)
 ids = torch.randint(2, cfg.vocab, (2, 128), generator=g)
 ids[:, 0] = 1
 
-def run(exchange, bf16):
+def run(exchange, bf16, rs=False):
     m.zero_grad()
-    m(input_ids=ids, labels=ids, return_logits=False)
+    out = m(input_ids=ids, labels=ids, return_logits=False)
+    losses.append(float(out.loss))
     ranges = []
     stage = None
     if bf16:
@@ -404,7 +405,7 @@ def run(exchange, bf16):
     def cb(off, cnt, ready):
         ranges.append((off, cnt))
         if exchange:
-            eng.allreduce_grads_async(off, cnt, bf16, ready)
+            (eng.reduce_scatter_grads_async if rs else eng.allreduce_grads_async)(off, cnt, bf16, ready)
     eng.set_option("grad_overwrite_next", 1)
     eng.backward(1.0, 1, cb)
     if exchange:
@@ -412,10 +413,21 @@ def run(exchange, bf16):
     torch.cuda.synchronize()
     return m.flat_grads.clone(), ranges, stage
 
+losses = []
 plain, ranges0, _ = run(False, False)
 eng.comm_init(Engine.comm_unique_id(), 0, 1)   # a 1-rank RCCL communicator: SUM is the identity
 f32, ranges1, _ = run(True, False)
 b16, ranges2, stage = run(True, True)
+# the reduce-scatter / all-gather form: with one rank the owned shard is the whole bucket and the gather is the identity
+f32_rs, ranges3, _ = run(True, False, rs=True)
+b16_rs, ranges4, _ = run(True, True, rs=True)
+assert ranges3 == ranges4 == ranges0 and torch.equal(f32_rs, plain) and torch.equal(b16_rs, b16)
+p0 = m.flat_params.clone()
+for off, cnt in sorted(ranges0):
+    eng.allgather_params_async(off, cnt)
+out = m(input_ids=ids, labels=ids, return_logits=False)   # waits for every gathered bucket before its first read
+torch.cuda.synchronize()
+assert torch.equal(m.flat_params, p0) and float(out.loss) == losses[0], (float(out.loss), losses[0])
 eng.comm_destroy()
 assert ranges0 == ranges1 == ranges2 and sum(c for _, c in ranges0) == eng.n_params
 assert torch.equal(plain, f32), float((plain - f32).abs().max())
