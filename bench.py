@@ -696,8 +696,13 @@ def main():
                                  # the recipe's own optimizer precision (/root/reference config/model/slam.yaml:9 torch_dtype bfloat16:
                                  # the HF Trainer builds AdamW on bf16 parameters, so the moments are bf16 too); the fp32-master
                                  # variant is measured after the timed region (`extras.fp32_master_optimizer`)
-                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16"))
+                                 optim_state_dtype=os.environ.get("SLAM_OPTIM_STATE_DTYPE", "bfloat16"),
+                                 # precision of the step's FINAL gradients: the recipe's own by default (bf16 parameters have
+                                 # bf16 .grad); SLAM_GRAD_DTYPE=float32 for the A/B
+                                 grad_dtype=os.environ.get("SLAM_GRAD_DTYPE") or None)
     trainer = SLAMTrainer(model=model, args=args)
+    if os.environ.get("SLAM_FINAL_MODE") is not None:   # A/B only: 0 = the round-5 step (fp32 gradients + chunked norm pass)
+        trainer._final_mode = int(os.environ["SLAM_FINAL_MODE"])
     nb = 4
     batches = [[synth_batch(rank, i * a.grad_accum + j, dev) for j in range(a.grad_accum)] for i in range(nb)]
     n_items = float(B * T * a.grad_accum)   # HF num_items_in_batch counts unshifted labels != -100

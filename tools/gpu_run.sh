@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call (rounds 4 and 5). Usage on the GPU box, from the repo root:
+# One gpurun call (rounds 4 - 6). Usage on the GPU box, from the repo root:
 #   bash tools/gpu_run.sh <tag> <stage> [<stage> ...]
 # stages:  t:<pytest -k expression>   targeted GPU tests        full          the whole -m gpu suite
 #          b:<name>[:ENV=V,ENV=V]     bench.py A/B line         smoke         __graft_entry__.smoke()
@@ -25,7 +25,7 @@ import json
 try:
     d = json.load(open("${O}_bench_${name}.json"))
     r = d.get("roofline", {})
-    print("${name}", d["value"], d["ms_per_step"], d["config"].get("final_loss"), r.get("frac"), (r.get("in_step") or {}).get("dominant_by_time"))
+    print("${name}", d["value"], d["ms_per_step"], d["config"].get("final_loss"), r.get("frac"), r.get("dominant_by_time"))
 except Exception as e:
     print("${name} FAILED", e)
 P
