@@ -259,7 +259,9 @@ int slam_cast_params(SlamEngine* h, const float* master_f32, slam_stream_t strea
  * slam_backward is the LAST of its optimizer step (HF Trainer: the micro-batch on which `sync_gradients` is true) - every kernel
  * that stores a final gradient value also emits its block's sum of squares for slam_grad_norm; with 2 the final values are
  * stored ONLY as bf16 into the slam_set_grad_image buffer (earlier micro-batches keep accumulating in fp32) and slam_grad_norm /
- * slam_adamw_step* read them there; resets itself. "bwd_wgrad_stream" (default
+ * slam_adamw_step* read them there; resets itself. The partial sums are not emitted by a backward that reports buckets to a callback
+ * (data parallel: the clip needs the norm of the EXCHANGED gradients - chunk sums after the exchange) nor under
+ * "grad_norm_partials" = 0 (slam_grad_norm then always runs the chunked pass, over whichever buffer holds the gradients). "bwd_wgrad_stream" (default
  * 1): slam_backward enqueues the weight-gradient GEMMs on an engine-owned second stream, ordered by events against the
  * dgrad chain on `stream`; `stream` is joined with it before slam_backward returns control of the gradient buffer (every
  * reported bucket range, and the end of the call). "overlap_adamw", "fuse_swiglu", "fuse_dswiglu", "gemm_256",

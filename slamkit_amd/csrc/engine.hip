@@ -92,6 +92,9 @@ struct SlamEngine {
   bf16_t* g16 = nullptr;        // gfinal == 2: where the gradients are
   float* gn_part = nullptr;     // sum-of-squares partials of the last final backward
   size_t gn_cap = 0, gn_used = 0;
+  int norm_partials = 1;        // "grad_norm_partials" = 0: never emit them (slam_grad_norm always takes the chunked pass)
+  bool gn_valid = false;        // ... and whether they describe the gradients the clip will see: not when that backward reported
+                                // buckets to a callback (data parallel: the norm is that of the EXCHANGED gradients, from chunk sums)
   int overlap_adamw = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr;
@@ -635,6 +638,7 @@ int slam_set_option(SlamEngine* h, const char* key, int64_t value) {
   }
   if (!strcmp(key, "time_families") && h) { h->time_families = value != 0; if (!value) h->fam_marks.clear(); return SLAM_OK; }
   if (!strcmp(key, "grad_overwrite_next") && h) { h->overwrite_next = value != 0; return SLAM_OK; }
+  if (!strcmp(key, "grad_norm_partials") && h) { h->norm_partials = value != 0; return SLAM_OK; }
   if (!strcmp(key, "grad_final_next") && h) {
     if (value < 0 || value > 2) return h->fail(SLAM_EINVAL, "grad_final_next takes 0, 1 or 2");
     h->final_next = (int)value;
@@ -775,7 +779,9 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->gfinal = 0;
   h->g16 = nullptr;
   if (fin == 2 && !IMG) return h->fail(SLAM_ESTATE, "grad_final_next = 2 needs slam_set_grad_image before the backward");
-  if (fin) {
+  const bool partials = fin && !cb && h->norm_partials;  // with a bucket callback the gradients are about to be exchanged: partials of the local ones are of no use
+  h->gn_valid = false;
+  if (partials) {
     CK((int)hipMemsetAsync(h->gn_part, 0, h->gn_cap * sizeof(float), st));  // blocks without a final store leave their slot alone
     h->gn_used = 0;
   }
@@ -783,13 +789,13 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   auto sink = [&]() -> GradSink* {  // the slots from gn_used on; take(r) after the launch
     if (!fin) return nullptr;
     sink_store.img_only = fin == 2;
-    sink_store.sumsq = h->gn_part + h->gn_used;
+    sink_store.sumsq = partials ? h->gn_part + h->gn_used : nullptr;
     sink_store.cap = (int)(h->gn_cap - h->gn_used);
     sink_store.used = 0;
     return &sink_store;
   };
   auto take = [&](int r) -> int {
-    if (fin && r == 0) h->gn_used += (size_t)sink_store.used;
+    if (partials && r == 0) h->gn_used += (size_t)sink_store.used;
     return r;
   };
 
@@ -916,14 +922,16 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
       // the scatter only touches the rows that occur in the batch (the others keep the head's contribution): this one tensor
       // gets its image from a conversion pass (which also emits its partials when the values kept are the rounded ones)
       const size_t ne = (size_t)VP * H;
-      if (fin == 2) {
+      if (fin == 2 && !partials) {
+        CK(f32_to_bf16(G + h->off_embed, IMG + h->off_embed, ne, ws));
+      } else if (fin == 2) {
         const int slots = f32_to_bf16_sumsq_slots(ne);
         if (h->gn_used + (size_t)slots > h->gn_cap) return h->fail(SLAM_ESTATE, "gradient-norm partial slots exhausted");
         CK(f32_to_bf16_sumsq(G + h->off_embed, IMG + h->off_embed, ne, h->gn_part + h->gn_used, ws));
         h->gn_used += (size_t)slots;
       } else {
         if (IMG) CK(f32_to_bf16(G + h->off_embed, IMG + h->off_embed, ne, ws));
-        if (fin == 1) {  // fp32 values kept: their chunk sums (the tensor starts the buffer: chunk-aligned, its end is `n` here)
+        if (partials) {  // fp32 values kept: their chunk sums (the tensor starts the buffer: chunk-aligned, its end is `n` here)
           const size_t slots = (ne + grad_chunk_elems() - 1) / grad_chunk_elems();
           if (h->gn_used + slots > h->gn_cap) return h->fail(SLAM_ESTATE, "gradient-norm partial slots exhausted");
           CK(grad_sumsq_chunks(G + h->off_embed, 0, ne, 0, ne, h->gn_part + h->gn_used, ws));
@@ -938,6 +946,7 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
   h->gfinal = fin;
   h->g16 = fin == 2 ? IMG : nullptr;
+  h->gn_valid = partials;
   return SLAM_OK;
 }
 
@@ -969,11 +978,15 @@ int slam_grad_norm(SlamEngine* h, float max_norm, float* norm_out, slam_stream_t
   if (!h || !norm_out) return SLAM_EINVAL;
   if (!h->grads || !h->ws) return h->fail(SLAM_ESTATE, "bind params and workspace first");
   CK(join_optimizer(h, (hipStream_t)stream));
-  if (h->gfinal) {  // the last backward emitted the partial sums of squares with its final-value stores: add them, in slot order
+  if (h->gn_valid) {  // the last backward emitted the partial sums of squares with its final-value stores: add them, in slot order
     CK(grad_norm_from_chunks(h->gn_part, h->gn_used, max_norm, norm_out, (hipStream_t)stream));
     return SLAM_OK;
   }
-  CK(grad_norm(h->grads, (size_t)h->n_params, max_norm, h->part_ws, norm_out, (hipStream_t)stream));
+  // chunk sums over the buffer the gradients are in (the bf16 image after a "grad_final_next" = 2 backward whose buckets were exchanged)
+  const int g16 = h->gfinal == 2;
+  const size_t n = (size_t)h->n_params;
+  CK(grad_sumsq_chunks(g16 ? (const void*)h->g16 : (const void*)h->grads, g16, n, 0, n, h->part_ws, (hipStream_t)stream));
+  CK(grad_norm_from_chunks(h->part_ws, (n + grad_chunk_elems() - 1) / grad_chunk_elems(), max_norm, norm_out, (hipStream_t)stream));
   return SLAM_OK;
 }
 
@@ -1055,11 +1068,17 @@ int slam_adamw_step_bf16(SlamEngine* h, void* exp_avg_bf16, void* exp_avg_sq_bf1
 // ---- sharded optimizer (data-parallel "rs_ag": reduce-scatter gradients, update the owned 1/N shard, all-gather bf16
 // parameters) ------------------------------------------------------------------------------------------------------
 int64_t slam_grad_chunk_elems(void) { return grad_chunk_elems(); }
+// element `offset` of the gradients, in the buffer the last backward left them in
+static void* range_grads(SlamEngine* h, int64_t offset) {
+  return h->gfinal == 2 ? (void*)(h->g16 + offset) : (void*)(h->grads + offset);
+}
 
 int slam_grad_sumsq_chunks(SlamEngine* h, int64_t offset, int64_t count, float* chunk_sums, slam_stream_t stream) {
   if (!h || !chunk_sums || offset < 0 || count < 0) return SLAM_EINVAL;
   if (!h->grads) return h->fail(SLAM_ESTATE, "no gradient buffer bound");
-  int r = grad_sumsq_chunks(h->grads, 0, (size_t)h->n_params, (size_t)offset, (size_t)count, chunk_sums, (hipStream_t)stream);
+  const int g16 = h->gfinal == 2;  // the gradients (a reduced shard of them) are in the bf16 image
+  int r = grad_sumsq_chunks(g16 ? (const void*)h->g16 : (const void*)h->grads, g16, (size_t)h->n_params, (size_t)offset, (size_t)count, chunk_sums,
+                            (hipStream_t)stream);
   if (r < 0) return h->fail(SLAM_EINVAL, "range must start on a chunk boundary and end on one (or at the end of the buffer)");
   CK(r);
   return SLAM_OK;
@@ -1081,7 +1100,7 @@ int slam_adamw_range(SlamEngine* h, int64_t offset, int64_t count, float* master
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw(master, h->params + offset, h->grads + offset, 0, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
+    CK(adamw(master, h->params + offset, range_grads(h, offset), h->gfinal == 2, m, v, (size_t)count, norm_out, lr, b1, b2, eps, wd, step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
 }
@@ -1095,8 +1114,8 @@ int slam_adamw_range_bf16_moments(SlamEngine* h, int64_t offset, int64_t count, 
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw_strided(1, master, h->params + offset, h->grads + offset, 0, m_bf16, v_bf16, (size_t)count, 1, 0, norm_out, lr, b1, b2, eps, wd,
-                     step, zero_grad, st));
+    CK(adamw_strided(1, master, h->params + offset, range_grads(h, offset), h->gfinal == 2, m_bf16, v_bf16, (size_t)count, 1, 0, norm_out, lr, b1, b2,
+                     eps, wd, step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
 }
@@ -1110,8 +1129,8 @@ int slam_adamw_range_bf16(SlamEngine* h, int64_t offset, int64_t count, void* m_
   hipStream_t st = (hipStream_t)stream;
   CK(join_optimizer(h, st));
   if (count)
-    CK(adamw_bf16(h->params + offset, h->grads + offset, 0, (bf16_t*)m_bf16, (bf16_t*)v_bf16, (size_t)count, norm_out, lr, b1, b2, eps,
-                  wd, step, zero_grad, st));
+    CK(adamw_bf16(h->params + offset, range_grads(h, offset), h->gfinal == 2, (bf16_t*)m_bf16, (bf16_t*)v_bf16, (size_t)count, norm_out, lr, b1, b2,
+                  eps, wd, step, zero_grad, st));
   h->params_t_dirty = h->params_t != nullptr;
   return SLAM_OK;
 }
@@ -1277,7 +1296,7 @@ int slam_allreduce_grads_async(SlamEngine* h, int64_t offset, int64_t count, int
   if (bf16_exchange) {
     bf16_t* img = h->last_grad_img + offset;
     e = r->AllReduce(img, img, (size_t)count, ncclBfloat16, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
-    if (e == ncclSuccess) CK(bf16_to_f32(img, h->grads + offset, (size_t)count, h->comm_stream));
+    if (e == ncclSuccess && h->gfinal != 2) CK(bf16_to_f32(img, h->grads + offset, (size_t)count, h->comm_stream));  // gfinal 2: read where they are
   } else {
     e = r->AllReduce(h->grads + offset, h->grads + offset, (size_t)count, ncclFloat32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
   }

@@ -500,7 +500,8 @@ class UnitLM(TokenLM):
     def backward(self, grad_scale: float = 1.0, bucket_layers: int = 0, bucket_cb=None, final: int = 0):
         """d(loss * grad_scale)/dparams accumulated into `flat_grads` (fp32). final = 1 | 2 marks the last backward of an
         optimizer step (engine option "grad_final_next"): the gradient-norm partials come out of the final-value stores, and
-        with 2 the final values are kept in bf16 only (`flat_grads16`; `named_grads` reads them there)."""
+        with 2 the final values are kept in bf16 only (`flat_grads16`; `named_grads` reads them there). With a bucket callback
+        (data parallel) `flat_grads16` is also the buffer that crosses the wire: the exchanged gradients stay in it."""
         if final == 2:
             self.engine.set_grad_image(self.enable_bf16_grads())
         self.engine.backward(grad_scale, bucket_layers, bucket_cb, final=final)

@@ -70,12 +70,18 @@ class GradBucketReducer:
         self.force = os.environ.get("SLAM_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
         self.time_buckets = False   # bracket every bucket's collective with timing events on the communication stream
         self._bucket_ev, self._last_bucket_ev = [], []
+        # round 6: the step's final gradients may LIVE in the bf16 image (engine option "grad_final_next" = 2, the reference's own
+        # gradient precision): then the reduced values stay in it - no widening pass; the norm and AdamW read them there
+        self.keep_bf16 = False
 
-    def arm_image(self):
+    def arm_image(self, keep_bf16: bool = False):
         """Before the backward whose buckets will be exchanged (the last micro-batch of a step): with a bf16 exchange and an
         engine that can do it, backward itself writes the bf16 communication image of the gradients (slam_set_grad_image) and
-        the per-bucket pack pass is skipped for this step."""
+        the per-bucket pack pass is skipped for this step. keep_bf16: the caller runs that backward with final = 2 - the image
+        then holds the ONLY copy of the step's gradients and the exchanged values stay there (no widening pass either).
+        Returns whether the image is armed."""
         self._image = False
+        self.keep_bf16 = False
         if (self.engine is None or not hasattr(self.engine, "set_grad_image") or self.comm_dtype != torch.bfloat16
                 or not self.flat.is_cuda or (self.world == 1 and not self.force) or os.environ.get("SLAM_DP_NO_IMAGE", "0") == "1"):
             return
@@ -83,6 +89,8 @@ class GradBucketReducer:
             self.stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
         self.engine.set_grad_image(self.stage)
         self._image = True
+        self.keep_bf16 = bool(keep_bf16)
+        return True
 
     def _pack(self, offset: int, count: int, st: torch.Tensor):
         """st[0:count] = comm_dtype(grads[offset:offset+count]) on the current stream."""
@@ -95,6 +103,8 @@ class GradBucketReducer:
 
     def _unpack(self, offset: int, count: int, st: torch.Tensor):
         """grads[offset:offset+count] = fp32(st[0:count]) on the current stream."""
+        if self.keep_bf16:
+            return  # the optimizer reads the reduced values in the image
         if self.engine is not None and self.flat.is_cuda and st.dtype == torch.bfloat16 and not ((offset | count) & 3):
             self.engine.unpack_grads_bf16(offset, count, st)
         else:
@@ -178,6 +188,7 @@ class GradBucketReducer:
                 w.wait()
         self.pending = []
         self._image = False
+        self.keep_bf16 = False
         self._last_bucket_ev, self._bucket_ev = self._bucket_ev, []
         covered = sorted(self.ranges)
         self.ranges = []
@@ -291,6 +302,7 @@ class ShardedGradReducer(GradBucketReducer):
         assert self._tail_done or self.top >= self.n, "the replicated tail was never exchanged"
         self.buckets, self.cut_hi, self.active, self._tail_done = [], self.top, False, False
         self._image = False
+        self.keep_bf16 = False
         covered = sorted(self.ranges)
         self.ranges = []
         return covered

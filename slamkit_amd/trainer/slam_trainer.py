@@ -65,6 +65,8 @@ class SLAMTrainer:
         # how the last backward of a step delivers its final values (UnitLM.backward(final=)): 2 = bf16 only, 1 = fp32; both
         # emit the gradient-norm partials from the final-value stores. Models without the hook (CPU stubs of the gloo tests): 0
         self._final_mode = (2 if gd == "bfloat16" else 1) if hasattr(model, "enable_bf16_grads") else 0
+        if self._final_mode:
+            model.engine.set_option("grad_norm_partials", 1 if getattr(self.args, "grad_norm_from_backward", True) else 0)
         self.exp_avg = torch.zeros(n, dtype=self.moment_dtype, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=self.moment_dtype, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -86,6 +88,10 @@ class SLAMTrainer:
             self._chunk_sums = torch.zeros(n_chunks, dtype=torch.float32, device=dev)
         else:
             self.reducer = GradBucketReducer(model.flat_grads, comm_dtype=getattr(torch, cd) if cd else None, engine=model.engine)
+        if self._final_mode == 2 and self.reducer.comm_dtype == torch.bfloat16:
+            # bf16 final gradients + bf16 exchange: ONE bf16 buffer is the gradient store, the communication image and the
+            # optimizer's input (training_step)
+            self.reducer.stage = model.enable_bf16_grads()
         if (self.world > 1 or self.reducer.force) and torch.device(dev).type == "cuda":
             from .. import check_hw_queues
             check_hw_queues(8)
@@ -117,8 +123,16 @@ class SLAMTrainer:
                             num_items_in_batch=num_items_in_batch, return_logits=False)
         loss = out.loss.detach()
         if last_micro and (self.world > 1 or self.reducer.force):
-            self.reducer.arm_image()  # bf16 exchange: this backward writes the communication image itself (no pack pass)
-            model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
+            # bf16 exchange: this backward writes the communication image itself (no pack pass); with bf16 final gradients the
+            # image is ALSO where they live: backward skips the fp32 stores, the reduced values stay in the image (no widening
+            # pass), the chunked norm and AdamW read them there
+            keep = (self._final_mode == 2 and type(self).optimizer_step is SLAMTrainer.optimizer_step
+                    and self.reducer.stage is getattr(model, "flat_grads16", None))
+            armed = self.reducer.arm_image(keep_bf16=keep)
+            if keep and armed:
+                model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket, final=2)
+            else:
+                model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket)
         elif last_micro and self._final_mode:
             model.backward(grad_scale, final=self._final_mode)  # norm partials (and bf16-only final values) from this backward
         else:

@@ -36,6 +36,7 @@ class SLAMTrainingArguments:
     ddp_algo: str = "all_reduce"                   # "all_reduce": every rank reduces and updates everything (torch DDP's scheme); "rs_ag": reduce-scatter gradients, AdamW on the owned 1/N shard, all-gather bf16 parameters under the next forward (dp.ShardedGradReducer)
     optim_state_dtype: str = "float32"             # "float32": fp32 master weights + fp32 Adam moments (30 B/param per step); "bfloat16": the recipe's own precision (slam.yaml:9) - bf16 parameters and moments updated in place, no master (16 B/param); "float32_bf16_moments": fp32 master + bf16 moments (22 B/param)
     grad_dtype: Optional[str] = None               # precision the FINAL gradients of an optimizer step are kept in for the clip and AdamW: "bfloat16" = the reference's own (bf16 parameters have bf16 .grad, slam.yaml:9): the last backward stores them in bf16 only and emits the norm partials from the same stores; "float32"; None = bfloat16 with optim_state_dtype bfloat16, else float32. Micro-batches always accumulate in fp32
+    grad_norm_from_backward: bool = True           # the clip's global norm from the sums of squares the last backward's final-value stores emit (no pass over the gradient buffer); False: the chunked norm pass - the summation order data-parallel runs use (they take the norm after the exchange), for bit-exact comparisons with them
     overwrite_first_grad: bool = True               # first backward of a step stores gradients (no zeroing pass); False = zero in AdamW
     overlap_optimizer: bool = False                # AdamW of the later layers under the next step's first layers (measured neutral: 272.7 vs 273.9 k tok/s)
     dataloader_num_workers: int = 0                # > 0: one background thread collates up to two optimizer steps ahead into pinned host memory (SLAMTrainer._micro_batches)
