@@ -60,6 +60,41 @@ def synth_batch(rank: int, i: int, device):
     return {"input_ids": ids, "labels": ids}
 
 
+def synth_packed_358m(rank: int, i: int, device):
+    """The recipe's own data mode at Slam-358M (/root/reference README.md:89 `data.packing=true`, slamkit/data/hf_dataset.py:61-62
+    DataCollatorWithFlattening; SURVEY.md §8d config 2 packed variant): ONE flattened row [1, 8192] per micro-batch, segment
+    lengths ~U{64..1024} (the last one cut to fit), position_ids restarting per segment, labels -100 at segment starts."""
+    g = torch.Generator().manual_seed(1234 + rank + 1000 * i)
+    total, ids, pos, lab, lens = B * T, [], [], [], []
+    while total > 0:
+        n = min(total, int(torch.randint(64, T + 1, (1,), generator=g)))
+        t = torch.randint(2, V, (n,), generator=g)
+        t[0] = 1
+        l = t.clone()
+        l[0] = -100
+        ids.append(t); pos.append(torch.arange(n)); lab.append(l); lens.append(n)
+        total -= n
+    cat = lambda xs: torch.cat(xs)[None].to(device)  # noqa: E731
+    return {"input_ids": cat(ids), "position_ids": cat(pos), "labels": cat(lab)}, lens
+
+
+def synth_padded_358m(rank: int, i: int, device):
+    """SURVEY.md §8d config 2 padded variant (DataCollatorForLanguageModeling, hf_dataset.py:63-64): [8, 1024] rows of lengths
+    ~U{256..1024}, right-padded with id 0, labels -100 on the padding, seed 4321."""
+    g = torch.Generator().manual_seed(4321 + rank + 1000 * i)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    lab = torch.full((B, T), -100, dtype=torch.long)
+    lens = []
+    for b in range(B):
+        n = int(torch.randint(256, T + 1, (1,), generator=g))
+        t = torch.randint(2, V, (n,), generator=g)
+        t[0] = 1
+        ids[b, :n] = t
+        lab[b, :n] = t
+        lens.append(n)
+    return {"input_ids": ids.to(device), "labels": lab.to(device)}, lens
+
+
 # --workload qwen1p5b (BASELINE.json configs[3], not the headline metric): Qwen2.5-1.5B-shaped body, mixed
 # unit + BPE vocabulary of 152,167 ids, ctx 2048, packed sequences (flattening collator layout)
 W4 = dict(name="Qwen/Qwen2.5-1.5B", vocab=152167, ctx=2048, tokens=16384, unit_lo=151667, n_mm=None)
@@ -317,10 +352,19 @@ def hbm_kernel_rates(model, trainer):
     else:
         us = _time_us(lambda: eng.adamw_step_bf16(trainer.exp_avg, trainer.exp_avg_sq, trainer.norm_out, 0.0, 0.9, 0.999, 1e-8, 0.0, 1000,
                                                   zero_grad=False), iters=5, warm=2)
+        g16 = getattr(trainer, "_final_mode", 0) == 2
         row("adamw_tile_kernel (bf16 parameters + bf16 moments in place, the recipe's precision; writes the transposed bf16 images itself)",
-            us, 18 * n, "16 B/param AdamW (fp32 grad read, bf16 p/m/v read + written) + 2 B/param transposed image")
+            us, (16 if g16 else 18) * n, ("14 B/param AdamW (bf16 grad, p, m, v read; p, m, v written)" if g16 else
+                                          "16 B/param AdamW (fp32 grad read, bf16 p/m/v read + written)") + " + 2 B/param transposed image")
     us = _time_us(lambda: eng.grad_norm(0.5, trainer.norm_out), iters=10, warm=2)
-    row("sumsq_partial_kernel + norm_finish_kernel (global gradient norm)", us, 4 * n, "4 B/param")
+    if getattr(trainer, "_final_mode", 0) and getattr(trainer.args, "grad_norm_from_backward", True) and not trainer.reducer.force:
+        # round 6: no pass over the gradients is left - backward's final-value stores emit ~60 k per-block sums of squares,
+        # this launch adds them (one block, fp64): latency, not bandwidth
+        out.append({"kernel": "norm_finish_kernel (global gradient norm from the partial sums backward's final-value stores emit)", "us": round(us, 2),
+                    "algorithmic_bytes": None, "GB_per_s": None, "frac_of_8TBps": None,
+                    "bytes": "~0.25 MB of partial sums; the 4 B/param pass of rounds 1-5 (0.245 ms) is gone"})
+    else:
+        row("sumsq_chunks_kernel + norm_finish_kernel (global gradient norm)", us, 4 * n, "4 B/param")
     return out
 
 
@@ -350,6 +394,7 @@ def extra_measurements(model, trainer, rank, dev, a):
         return {"tokens_per_s": round(world * B * T * ga * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
 
     res["grad_accum_16"] = run(trainer, 16, 3, 1)
+    res.update(recipe_data_modes(model, trainer, rank, dev, world))
     # the boundary as the training loop crosses it: rows collated on the host (DataCollatorForLanguageModeling), CPU int64
     # batches handed to UnitLM.forward (pageable H2D inside the step), token counts taken from the CPU labels
     from slamkit_amd.data import DataCollatorForLanguageModeling
@@ -381,6 +426,60 @@ def extra_measurements(model, trainer, rank, dev, a):
     else:
         tr2 = SLAMTrainer(model=model, args=args2)  # drops the fp32 master: the bf16 parameters become the only copy
         res["recipe_optimizer_bf16_state"] = run(tr2, 1, max(5, min(a.steps, 20)), 3)
+    return res
+
+
+def recipe_data_modes(model, trainer, rank, dev, world):
+    """The recipe's own data modes at Slam-358M, through SLAMTrainer.optimizer_step (VERDICT r5 missing #3): `packed_ga16` -
+    data.packing=true with gradient_accumulation_steps=16 (/root/reference README.md:89), one flattened [1, 8192] row per
+    micro-batch; `padded` - right-padded [8, 1024] rows (the non-packing collator). tokens_per_s counts non-ignored labels
+    (SLAMTrainer.get_num_tokens, slam_trainer.py:59-65); positions_per_s counts every position the kernels process. The
+    attention kernels see short segments / ragged rows here; their in-step durations come from one instrumented step."""
+    res = {}
+
+    def measure(name, micro_sets, steps, warm, what):
+        counts = [float(sum(int((mb["labels"] != -100).sum()) for mb in ms)) for ms in micro_sets]
+        positions = [sum(int(mb["input_ids"].numel()) for mb in ms) for ms in micro_sets]
+        for i in range(warm):
+            trainer.optimizer_step(micro_sets[i % len(micro_sets)], 1e-3, counts=(counts[i % len(counts)],) * 2)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok = pos = 0
+        for i in range(steps):
+            k = i % len(micro_sets)
+            trainer.optimizer_step(micro_sets[k], 1e-3, counts=(counts[k],) * 2)
+            tok += counts[k]
+            pos += positions[k]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # one more step with timing events around every launch: the attention kernels on THIS data
+        model.engine.set_option("time_families", 1)
+        trainer.optimizer_step(micro_sets[0], 1e-3, counts=(counts[0],) * 2)
+        fam = {}
+        for nm, ms_ in model.engine.family_ms():   # the marks of the step's LAST micro-batch
+            fam.setdefault(nm, []).append(ms_)
+        model.engine.set_option("time_families", 0)
+        us = lambda k: round(sum(fam.get(k, [0.0])) / max(1, len(fam.get(k, [0.0]))) * 1e3, 1)  # noqa: E731
+        res[name] = {"tokens_per_s": round(world * tok / dt, 1), "positions_per_s": round(world * pos / dt, 1),
+                     "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_micro_batch": round(dt / steps / len(micro_sets[0]) * 1e3, 3),
+                     "steps": steps, "micro_batches_per_step": len(micro_sets[0]),
+                     "in_step_us": {"attn_fwd": us("attn_fwd"), "attn_bwd": us("attn_bwd"), "qkv_fwd": us("qkv_fwd"), "gateup_fwd": us("gateup_fwd"),
+                                    "loss": us("loss")},
+                     "what": what}
+
+    packed = [[synth_packed_358m(rank, 300 + 16 * s_ + j, dev) for j in range(16)] for s_ in range(2)]
+    seg = [n for ms in packed for _, lens in ms for n in lens]
+    measure("packed_ga16", [[mb for mb, _ in ms] for ms in packed], 3, 1,
+            f"data.packing=true, GA 16 (README.md:89): flattened [1, 8192] rows, segment lengths U{{64..1024}} (mean {sum(seg) / len(seg):.0f}), "
+            "labels -100 at segment starts, seed 1234 + rank")
+    padded = [[synth_padded_358m(rank, 400 + s_, dev)] for s_ in range(4)]
+    fill = sum(n for ms in padded for _, lens in ms for n in lens) / (len(padded) * B * T)
+    measure("padded", [[mb for mb, _ in ms] for ms in padded], 10, 3,
+            f"right-padded [8, 1024] rows, lengths U{{256..1024}} ({100 * fill:.0f} % of the positions are tokens), labels -100 on the padding, seed 4321")
     return res
 
 

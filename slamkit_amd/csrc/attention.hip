@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * 128;
   if (p.prio && p.perm) set_rank_prio(bi.slot, (M + 127) / 128);
-  const int qw0 = q0 + wave * 32;
+  // the wave index as an SGPR: everything derived from it (the wave's first query row, "this tile is above my diagonal",
+  // "this tile needs masks") is then a scalar compare + s_cbranch instead of v_cmp + exec-mask save / restore around the body
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int qw0 = q0 + wv * 32;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
@@ -208,7 +211,6 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   off.init(ld, tid);
   FragOff fo;
   fo.init(l15, g);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
   // running tile pointers (wave-uniform): one 64-bit add per operand per tile
   const size_t tstep = (size_t)64 * ld;
   const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
@@ -259,7 +261,9 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
   // moved lse2 by 2e-4 relative and the 200-step loss curve by 0.3 % at single steps; measured and taken back out.)
   f32x4_t ot[4 * ND][2], negm[2];
   float lsum[2] = {0.f, 0.f};
-  bool started[2] = {false, false};
+  // the running max moves when the tile's row max exceeds thr: "any visible key" until the row has seen its first one
+  // (m becomes the true row max then), m + 8 afterwards - ONE compare per row block and tile (round 5: a flag, two compares, selects)
+  float thr[2] = {0.5f * NEG_BIG, 0.5f * NEG_BIG};
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     negm[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};  // m = 0 until the row has seen its first visible key ("started")
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][j][r]);
       mloc[j] = mx;
-      grow |= (mx > 8.0f) | (!started[j] & (mx > 0.5f * NEG_BIG));
+      grow |= mx > thr[j];
     }
     if (__any(grow)) {
 #pragma unroll
@@ -327,10 +331,10 @@ __global__ __launch_bounds__(256, FwdCfg<ND>::OCC) void attn_fwd_kernel(AttnArgs
         float mx = mloc[j];
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (mx > 0.5f * NEG_BIG) {  // the row sees a key in this tile (the same for the four lanes of a row)
-          const float shift = started[j] ? -fmaxf(mx, 0.f) : -mx;  // m_old - m_new: m grows by max(mx, 0) once started; becomes the true max before
-          const float alpha = started[j] ? fast_exp2(shift) : 1.f;  // (nothing accumulated yet before the first key: exp2(-mx) may be inf)
-          started[j] = true;
+        if (mx > thr[j]) {  // this row's max moves (the same decision in the four lanes of a row): m += mx
+          const float shift = -mx;                                     // m_old - m_new
+          const float alpha = thr[j] > 0.f ? fast_exp2(shift) : 1.f;  // (nothing accumulated yet before the first key: exp2(-mx) may be inf)
+          thr[j] = 8.0f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) negm[j][r] += shift;
           lsum[j] *= alpha;
@@ -421,7 +425,8 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
   const int h = bi.h, kvh = bi.kvh;
   const int q0 = (p.perm ? p.perm[bi.slot] : bi.slot) * QT;
   if (p.prio && p.perm) set_rank_prio(bi.slot, (M + QT - 1) / QT);
-  const int qw0 = q0 + wave * WR;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);  // SGPR: the wave-uniform tile tests below become scalar branches
+  const int qw0 = q0 + wv * WR;
   const bf16_t* Qb = p.qkv + h * D;
   const bf16_t* Kb = p.qkv + (p.nH + kvh) * D;
   const bf16_t* Vb = p.qkv + (p.nH + p.nKV + kvh) * D;
@@ -435,7 +440,6 @@ __global__ __launch_bounds__(256, (DqCfg<ND, JQ>::OCC)) void attn_bwd_dq_kernel(
   off.init(ld, tid);
   FragOff fo;
   fo.init(l15, g);
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const size_t tstep = (size_t)64 * ld;
   const bf16_t* kp = Kb + (size_t)kt_begin * tstep;
   const bf16_t* vp = Vb + (size_t)kt_begin * tstep;
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
   uint4 kf[KW][2 * ND], vf[KW][2 * ND];
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
-    key[i] = k0 + wave * WK + i * 16 + l15;
+    key[i] = k0 + wv * WK + i * 16 + l15;
     const int kc = key[i] < M ? key[i] : M - 1;
 #pragma unroll
     for (int ds = 0; ds < 2 * ND; ++ds) {
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(256, (DkvCfg<ND, KW>::OCC)) void attn_bwd_dkv_kerne
     for (int fd = 0; fd < 4 * ND; ++fd) { dk[i][fd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[i][fd] = dk[i][fd]; }
   wait_all_loads_visible();
 
-  const int kw0 = k0 + wave * WK;
+  const int kw0 = k0 + wv * WK;  // SGPR (wv): the tile tests below are scalar branches
   int stage = 0, tq = 0;
   for (int t = 0; t < n; ++t) {
     if (NST >= 3 && t + 1 < n) wait_vmcnt<NDMA>();

@@ -67,7 +67,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
       {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_256_persist_cus", &t->g256_persist_cus, 0, 4096}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}};
+      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_256_persist_cus", &t->g256_persist_cus, 0, 4096}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}, {"gemm_256_roles", &t->g256_roles, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -380,6 +380,106 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
         st_out(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, pack_bf16x8(a8), p.nt_store);
       }
     }
+  }
+}
+
+// ---- role-split epilogue of the persistent 256 x 256 kernel (round 6, "gemm_256_roles") -------------------------------------------
+// One 64-row quadrant of a wave's 128 x 64 output as a list of 16-byte RECORDS - exactly what epilogue8<LEAN> stores, in its
+// order and with its arithmetic: plain [fm][q] {C}; SwiGLU forward [fm][q] {C} then [fm] {act}; SwiGLU backward [fm][q]
+// {d gate, d up}. quad_emit computes them (TO_LDS: into the lane's slots of a staging region instead of memory); quad_drain
+// reads staged records and stores them where quad_emit<false> of the producing wave would have - the two loop nests are the
+// same by construction.
+SLAM_DEVICE uint4 lds_rec_read(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+template <bool TO_LDS>
+SLAM_DEVICE void quad_emit(const GemmArgs& p, const f32x4_t (&acc)[4][4], int row0, int col0, int wn, int l15, int g, char* stg) {
+  const int cw = col0 + wn * 64 + g * 8;
+  auto out = [&](int k, bf16_t* ptr, const uint4& v) {
+    if (TO_LDS) *reinterpret_cast<uint4*>(stg + k * 1024) = v;
+    else st_out(ptr, v, p.nt_store);
+  };
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + fm * 16 + l15;
+    const size_t rowoff = (size_t)m * p.ldc;
+    if (p.gu) {
+      bf16_t* grow = p.gu + (size_t)m * (2 * p.Cn);
+      uint4 gg[2], uu[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cw + 32 * q;
+        const bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+        gg[q] = *reinterpret_cast<const uint4*>(gp);
+        uu[q] = *reinterpret_cast<const uint4*>(gp + 32);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cw + 32 * q;
+        float gv[8], uv[8], dg[8], du[8];
+        unpack_bf16x8(gg[q], gv);
+        unpack_bf16x8(uu[q], uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = acc[fm][2 * q + (e >> 2)][e & 3];
+          const float sg = fast_sigmoid(gv[e]);
+          du[e] = d * gv[e] * sg;
+          dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+        }
+        bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+        out((fm * 2 + q) * 2, gp, pack_bf16x8(dg));
+        out((fm * 2 + q) * 2 + 1, gp + 32, pack_bf16x8(du));
+      }
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[fm][2 * q + (e >> 2)][e & 3];
+      out(fm * 2 + q, reinterpret_cast<bf16_t*>(p.C) + rowoff + cw + 32 * q, pack_bf16x8(v));
+    }
+    if (p.act) {
+      float a8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gt = acc[fm][e >> 2][e & 3], up = acc[fm][2 + (e >> 2)][e & 3];
+        a8[e] = gt * fast_sigmoid(gt) * up;
+      }
+      out(8 + fm, p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, pack_bf16x8(a8));
+    }
+  }
+}
+SLAM_DEVICE void quad_drain(const GemmArgs& p, int row0, int col0, int wn, int l15, int g, const char* stg) {
+  const int cw = col0 + wn * 64 + g * 8;
+  if (p.gu) {
+    uint4 r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = lds_rec_read(stg + k * 1024);
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      bf16_t* grow = p.gu + (size_t)(row0 + fm * 16 + l15) * (2 * p.Cn);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cw + 32 * q;
+        bf16_t* gp = grow + (c >> 5) * 64 + (c & 31);
+        st_out(gp, r[(fm * 2 + q) * 2], p.nt_store);
+        st_out(gp + 32, r[(fm * 2 + q) * 2 + 1], p.nt_store);
+      }
+    }
+    return;
+  }
+  uint4 r[12];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = lds_rec_read(stg + k * 1024);
+  if (p.act) {
+#pragma unroll
+    for (int k = 8; k < 12; ++k) r[k] = lds_rec_read(stg + k * 1024);
+  }
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int m = row0 + fm * 16 + l15;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) st_out(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + cw + 32 * q, r[fm * 2 + q], p.nt_store);
+    if (p.act) st_out(p.act + (size_t)m * (p.Cn / 2) + (col0 + wn * 64) / 2 + g * 8, r[8 + fm], p.nt_store);
   }
 }
 
@@ -915,11 +1015,24 @@ SLAM_DEVICE void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // MF32 (round 5): the same schedule on v_mfma_f32_32x32x16_bf16 - a phase is 2 (32-row blocks) x 1 (32-column block) x 4
 // K-steps of 16 = 8 MFMAs of 32 cycles instead of 16 of ~17; the same 12 ds_read_b128 per phase (a fragment is now 32 rows
 // x 16 k instead of 16 x 32), the same LDS images; column-tile rows in the perm32 order, epilogue32.
-template <bool PERSIST, bool MF32>
+// ROLES (round 6, PERSIST && !MF32 only, "gemm_256_roles"): loads and stores share ONE in-order vmcnt per wave, so a wave that
+// has just stored its tile cannot use a counted wait for the next K-tiles until those stores have drained - the 256 resident
+// blocks sit through their store bursts together (profiles/r5_experiments/README.md section 1: +20 ... +72 % cycles). The
+// two wave rows take different jobs instead (one wave of each row per SIMD):
+//   wave row 0 = LOADERS: issue EVERY LDS-DMA of the block (4 per half-tile instead of 2) and do every counted wait - their
+//                vmcnt only ever holds loads; they never store to memory: a finished quadrant goes to LDS as 16-byte records
+//                (quad_emit<true>) into the K-tile buffer that is free at the tile boundary;
+//   wave row 1 = STORERS: issue no load in the K loop and execute no vmcnt wait there (the barriers publish the loaders'
+//                waits, as they always did for the other waves' slices); they store their own quadrants and the loaders'
+//                records (quad_drain) and run on into the next tile's K loop with the stores in flight.
+// Four barriers per tile on top of the schedule (records visible / staging region free, per 64-row quadrant).
+template <bool PERSIST, bool MF32, bool ROLES = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
+  static_assert(!ROLES || (PERSIST && !MF32), "role split: persistent 16x16x32 kernel only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = 128 * 128;      // half-tile bytes: 128 rows x 128 B
   constexpr int KT = 4 * HT;         // K-tile buffer
+  constexpr int NDMA = ROLES ? 4 : 2;  // LDS-DMA instructions per half-tile and issuing wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, g = lane >> 4;
@@ -966,16 +1079,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   const int nk = p.Kc / BK;
   const uint32_t lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  // DMA source offsets, 2 chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
-  uint32_t vo[4][2];
+  const bool loader = !ROLES || wv < 4;  // wave-uniform (SGPR)
+  // DMA source offsets, NDMA chunks per lane per half-tile; half-tile order in a buffer: Amq0 | Bnq0 | Bnq1 | Amq1
+  uint32_t vo[4][NDMA];
   // fragment addresses inside a half-tile: byte offsets of row (wave block + f*16 + l15), without the chunk term
   int ka, offA[4], offB[2];
   // per-lane constants of the K loop. A persistent block computes them again after every epilogue (from an opaque copy
   // of the thread id, so that the compiler cannot keep the first set alive): they stay out of the epilogue's live range
   auto lane_setup = [&](int t_) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int P = i * 512 + t_, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
+    for (int i = 0; i < NDMA; ++i) {
+      const int P = ROLES ? i * 256 + (t_ & 255) : i * 512 + t_, r = P >> 3, c = (P & 7) ^ lds_swz_key(r);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int grow = (r >> 6) * 128 + h * 64 + (r & 63);          // relative to the tile origin: 32-bit offsets must not
@@ -1003,10 +1117,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
   lane_setup(tid);
   // h: position in the buffer (0 Amq0, 1 Bnq0, 2 Bnq1, 3 Amq1); ta / tb: the K-tile's origin in A / B; par: buffer
   auto issue_half = [&](int h, const bf16_t* ta, const bf16_t* tb, int par) {
+    if (ROLES && !loader) return;
     const bf16_t* base = (h == 0 || h == 3) ? ta : tb;
     const uint32_t dst = lds0 + (uint32_t)(par * KT + h * HT) + (uint32_t)wv * 1024u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * 8192)));
+    for (int i = 0; i < NDMA; ++i) glds16_sv(base, vo[h][i], __builtin_amdgcn_readfirstlane(dst + (uint32_t)(i * (ROLES ? 4096 : 8192))));
+  };
+  // counted waits: the loaders' counts are in units of their 4 DMAs per half-tile; storers never wait on vmcnt in the K loop
+  auto wait_phase = [&](auto last_tag, int which) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    if constexpr (ROLES) {
+      if (!loader) return;
+      if (which == 0) { if (LAST) wait_vmcnt<4>(); else wait_vmcnt<8>(); }
+      else if (which == 1) { if (LAST) wait_vmcnt<0>(); else wait_vmcnt<8>(); }
+      else { if (!LAST) wait_vmcnt<8>(); }
+    } else {
+      wait_ph<LAST>(which);
+    }
   };
 
   f32x4_t acc[2][4][4];      // 16x16x32 form (dead in the MF32 instantiation)
@@ -1098,14 +1225,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     if (!LAST) issue_half(0, na, nb, par ^ 1);
     read_A(buf);
     read_B(buf + HT, 0);
-    if (MODE != 2) wait_ph<LAST>(0);  // Bnq1(t) landed -> read in phase 2
+    if (MODE != 2) wait_phase(std::integral_constant<bool, LAST>{}, 0);  // Bnq1(t) landed -> read in phase 2
     raw_barrier();
     mma(0, 0);
     barrier_b();
     // phase 2
     if (!LAST) issue_half(1, na, nb, par ^ 1);
     read_B(buf + 2 * HT, 1);
-    if (MODE != 2) wait_ph<LAST>(1);  // Amq1(t) landed -> read in phase 3
+    if (MODE != 2) wait_phase(std::integral_constant<bool, LAST>{}, 1);  // Amq1(t) landed -> read in phase 3
     raw_barrier();
     mma(0, 1);
     barrier_b();
@@ -1117,7 +1244,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     barrier_b();
     // phase 4
     if (!LAST) issue_half(3, na, nb, par ^ 1);
-    wait_ph<LAST>(2);  // Amq0(t+1), Bnq0(t+1) landed -> read in phase 1 of the next K-tile
+    wait_phase(std::integral_constant<bool, LAST>{}, 2);  // Amq0(t+1), Bnq0(t+1) landed -> read in phase 1 of the next K-tile
     raw_barrier();
     mma(1, 0);
     barrier_b();
@@ -1146,7 +1273,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
     // one loop body for every tile (no variant diamonds: the accumulators keep their registers): the first K-tile of a
     // tile finds its half-tiles drained, the last one issues the next tile's first K-tile - or, on the block's last tile,
     // this tile's first K-tile once more (64 KB of L2 reads per block, never consumed)
-    wait_vmcnt<0>();
+    if (loader) wait_vmcnt<0>();
     raw_barrier();
     int par = 0;
     for (;;) {
@@ -1166,11 +1293,29 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
       ktile(par, steady_t{}, ta, tb);  // the DMA stream runs on into the next tile
       par ^= 1;
       if (wr == 0) raw_barrier();  // balance the barrier count: both wave rows leave the tile together
-      wait_vmcnt<0>();             // this wave's pieces of the next tile's first K-tile (see MODE 2)
+      if (loader) wait_vmcnt<0>();  // this wave's pieces of the next tile's first K-tile (see MODE 2)
       int l15e = MF32 ? l31 : l15, ge = MF32 ? hh : g;
       asm volatile("" : "+v"(l15e), "+v"(ge));  // keeps the epilogue's address arithmetic out of the K loop
-      store_quadrant(std::true_type{}, 0, l15e, ge);
-      store_quadrant(std::true_type{}, 1, l15e, ge);
+      if constexpr (ROLES) {
+        // staging: the K-tile buffer the last K-tile was read from (the next tile's first K-tile sits in the other one and the
+        // first DMA into this one is issued after the last barrier below); 16 KB per wave column, record k of lane l at k KB + 16 l
+        char* stg = smem + (par ^ 1) * KT + wc * 16384 + lane * 16;
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+          if (loader) {
+            quad_emit<true>(p, acc[mq], row0 + mq * 64, col0, wc, l15e, ge, stg);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          } else {
+            quad_emit<false>(p, acc[mq], row0 + 128 + mq * 64, col0, wc, l15e, ge, nullptr);  // own rows, beside the loaders' conversion
+          }
+          raw_barrier();  // the loaders' records are in LDS
+          if (!loader) quad_drain(p, row0 + mq * 64, col0, wc, l15e, ge, stg);
+          raw_barrier();  // the staging region is free again (next quadrant / the DMA of the next tile's second K-tile)
+        }
+      } else {
+        store_quadrant(std::true_type{}, 0, l15e, ge);
+        store_quadrant(std::true_type{}, 1, l15e, ge);
+      }
       if (!has_next) break;
       zero_acc();
       nid = nnext; row0 = nrow0; col0 = ncol0;
@@ -2098,6 +2243,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
     if (e != hipSuccess) return (int)e;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
@@ -2132,7 +2278,8 @@ static int launch_256(GemmArgs a, hipStream_t st) {
     if (persist) gemm_nt_256_kernel<true, true><<<cus, 512, 8 * 128 * 128, st>>>(a);
     else gemm_nt_256_kernel<false, true><<<tiles, 512, 8 * 128 * 128, st>>>(a);
   } else {
-    if (persist) gemm_nt_256_kernel<true, false><<<cus, 512, 8 * 128 * 128, st>>>(a);
+    if (persist && T().g256_roles) gemm_nt_256_kernel<true, false, true><<<cus, 512, 8 * 128 * 128, st>>>(a);
+    else if (persist) gemm_nt_256_kernel<true, false><<<cus, 512, 8 * 128 * 128, st>>>(a);
     else gemm_nt_256_kernel<false, false><<<tiles, 512, 8 * 128 * 128, st>>>(a);
   }
   return (int)hipGetLastError();

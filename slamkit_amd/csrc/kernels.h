@@ -35,6 +35,10 @@ struct GemmTune {
   // under the board's power limit; Slam-358M step 330.7 k (8 waves) / 323.4 k (4 waves) vs 338.8 k tokens/s
   int mf32 = 0;
   int g256_w4 = 0;              // 256 x 256 tiles on the persistent four-wave kernel (128 x 128 per wave; needs mf32)
+  // round 6: the persistent 256 x 256 kernel with its two wave rows as LOADERS (every LDS-DMA, every counted wait, results handed
+  // over through LDS) and STORERS (every output store, no vmcnt wait in the K loop): the store drain of a tile runs under the
+  // next tile's K loop instead of in front of it (loads and stores share one in-order vmcnt per wave)
+  int g256_roles = 0;
 };
 GemmTune* gemm_default_tune();
 GemmTune* gemm_use_tune(GemmTune* t);  // install t (NULL = process default) for this thread; returns the previous one

@@ -306,6 +306,37 @@ def test_rope(packed, hd):
     check("rope bwd(fwd(x)) == x", buf.float(), qkv, 6e-3, 3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 8192, 192), (4352, 4096, 64 * 5), (8192, 9728, 896), (8192, 4864, 896), (4096, 4864, 128)])
+def test_gemm_nt_256_loader_storer_roles(M, N, K):
+    """gemm_256_roles (round 6): the persistent 256 x 256 kernel with one wave row issuing every LDS-DMA and handing its results
+    over through LDS, the other storing everything - the same tiles, the same contraction order, the same epilogue arithmetic:
+    plain, fused-SwiGLU-forward and fused-SwiGLU-backward outputs must equal the undivided persistent kernel's BIT FOR BIT
+    (twice: the staging region is reused across tiles), on grids with ragged last rounds and at the step's own shapes."""
+    X, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    GU = rnd(M, 2 * N, seed=5)
+    Xd, Wd, gud = dev_bf16(X), dev_bf16(W), dev_bf16(GU)
+    outs = {}
+    try:
+        assert lib().slam_set_option(None, b"gemm_256", 2) == 0
+        for roles in (0, 1, 1):
+            assert lib().slam_set_option(None, b"gemm_256_roles", roles) == 0
+            Yp = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert lib().slam_op_gemm_nt(ptr(Xd), ptr(Wd), ptr(Yp), None, None, M, N, K, 2, stream()) == 0
+            Ys = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            act = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+            assert lib().slam_op_gemm_nt_swiglu(ptr(Xd), ptr(Wd), ptr(Ys), ptr(act), M, N, K, stream()) == 0
+            g = gud.clone()
+            assert lib().slam_op_gemm_nt_dswiglu(ptr(Xd), ptr(Wd), ptr(g), M, N, K, stream()) == 0
+            sync()
+            outs.setdefault(roles, []).append((Yp, Ys, act, g))
+    finally:
+        lib().slam_set_option(None, b"gemm_256_roles", 0)
+        lib().slam_set_option(None, b"gemm_256", 1)
+    for run in outs[1]:
+        for name, a, b in zip(("plain", "swiglu C", "swiglu act", "dswiglu"), outs[0][0], run):
+            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ"
+
+
 # ---------------------------------------------------------------------------------------- SwiGLU
 def test_swiglu():
     M, I = 130, 512

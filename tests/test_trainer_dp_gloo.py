@@ -185,3 +185,73 @@ def test_slam_trainer_world2_gloo(tmp_path):
     for rank, _, flags, flags0 in res:
         assert flags == (True, True, True) and flags0 == (False, False, False)
     assert res[0][1][True][0] == res[1][1][True][0]  # both ranks hold the same parameters, bit for bit
+
+
+# ---- early exit with a collective still posted (round-5 advisor finding) -----------------------------------------------------------
+def _early_worker(rank, world, port, q, tmp):
+    """max_steps = 2 of the 3 optimizer steps an epoch holds: when the loop leaves, the token-count all-reduce of step 3 has
+    been POSTED (one step ahead) and not consumed. Evaluate + save fire at that same step and a stopper callback fires on rank 1
+    only: the drain must come before their collectives (evaluate's all-reduce, save's barrier, the control sync) or the ranks
+    pair mismatching collectives and hang / corrupt the counts. (Over gloo an undrained work object completes by itself, so
+    this checks the early-exit path end to end - no hang, same step, same state, every later collective paired - rather than
+    failing on the missing wait alone.)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slamkit_amd.data import DataCollatorForLanguageModeling
+        from slamkit_amd.trainer import SLAMTrainer, SLAMTrainingArguments
+        from slamkit_amd.trainer.callbacks import TrainerCallback
+
+        class StopOnRank1(TrainerCallback):
+            def on_step_end(self, args, state, control, **kw):
+                if rank == 1 and state.global_step == 2:
+                    control.should_training_stop = True
+
+        out = {}
+        for name, kw in (("max_steps", dict(max_steps=2, save_steps=2, eval_strategy="steps", eval_steps=2)),
+                         ("stopper", dict(max_steps=-1, num_train_epochs=1.0, save_steps=2, eval_strategy="steps", eval_steps=2))):
+            args = SLAMTrainingArguments(output_dir=os.path.join(tmp, f"{name}_r{rank}"), per_device_train_batch_size=2,
+                                         gradient_accumulation_steps=2, learning_rate=1e-2, warmup_steps=1, warmup_ratio=0.0,
+                                         logging_steps=1, ddp_bucket_layers=1, seed=5, ddp_comm_dtype="float32", **kw)
+            model = StubLM()
+            type(model)._weights = property(lambda self: self.flat_master)
+            rows = make_rows()
+            tr = SLAMTrainer(model=model, args=args, data_collator=DataCollatorForLanguageModeling(pad_token_id=0), train_dataset=rows,
+                             eval_dataset=rows[:6], callbacks=[StopOnRank1()] if name == "stopper" else [])
+            posted = []
+            orig = tr.post_counts
+            tr.post_counts = lambda a, b: (posted.append(1), orig(a, b))[1]
+            tr.train()
+            ev = [h for h in tr.state.log_history if "eval_loss" in h]
+            out[name] = (tr.state.global_step, model.flat_master.tolist(), len(posted), [e["eval_loss"] for e in ev], len(model.saved),
+                         tr.state.num_input_tokens_seen)
+        # the group is still usable and in step: one more collective pairs up
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        q.put((rank, out, float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_early_exit_drains_the_posted_count_collective_world2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_early_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))   # a hang here IS the regression
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, o0, s0), (r1, o1, s1) = res
+    assert s0 == s1 == 3.0
+    for name in ("max_steps", "stopper"):
+        step0, p0, posted0, ev0, saved0, seen0 = o0[name]
+        step1, p1, posted1, ev1, saved1, seen1 = o1[name]
+        assert step0 == step1 == 2, (name, step0, step1)            # both ranks stop at the same step (rank 1's stopper included)
+        assert p0 == p1                                               # identical parameters
+        assert posted0 == posted1 == 3                                # the collective of the step that never ran WAS posted ...
+        assert ev0 == ev1 and len(ev0) == 1                          # ... and evaluate's all-reduce still paired up (same global loss)
+        assert saved0 == 1 and saved1 == 0                           # rank 0 saved, both passed the barrier
+        assert seen0 == seen1 > 0
