@@ -12,13 +12,13 @@ bash tools/gpu_run.sh ${tag} smoke
 python -c "import json;d=json.load(open('${O}_bench_driver.json'));print('bench (driver command)', d['value'], d['ms_per_step'], d['config']['ms_per_step_median_50'])"
 python -c "import json;d=json.load(open('${O}_bench_default.json'));print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'])"
 cd /tmp
-SLAM_BENCH_MEDIAN_STEPS=5 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_prof -o r5 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > ${O}_prof.log 2>&1
+SLAM_BENCH_MEDIAN_STEPS=5 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_prof -o r6 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > ${O}_prof.log 2>&1
 cd $R; find ${O}_prof -name "*.csv" | head
 bash tools/pmc_step.sh ${tag} slam358m
 (timeout 400 python bench.py --workload qwen1p5b --steps 5 --warmup 2 2>${O}_bench_q.err | tail -1) > ${O}_bench_q.json
 python -c "import json;d=json.load(open('${O}_bench_q.json'));print('qwen', d['value'], d['ms_per_step'])"
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_profq -o r5q -- python $R/bench.py --workload qwen1p5b --steps 3 --warmup 1 > ${O}_profq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_profq -o r6q -- python $R/bench.py --workload qwen1p5b --steps 3 --warmup 1 > ${O}_profq.log 2>&1
 cd $R; find ${O}_profq -name "*.csv" | head -4
 (timeout 300 python bench.py --workload dpo --steps 10 --warmup 3 2>${O}_bench_dpo.err | tail -1) > ${O}_bench_dpo.json
 python -c "import json;d=json.load(open('${O}_bench_dpo.json'));print('dpo', d['value'], d['ms_per_step'])"

@@ -73,7 +73,7 @@ gaps = collections.defaultdict(list)
 for st in steps:
     t0 = st[0][0]
     t_ce = max(r[1] for r in st if short(r[2]).startswith(("ce_", "loss_finish")))
-    t_opt = min(r[0] for r in st if "sumsq" in r[2] or "adamw" in r[2])
+    t_opt = min(r[0] for r in st if "sumsq_chunks" in r[2] or "norm_finish" in r[2] or "adamw" in r[2])  # round 6: the norm is the finish kernel alone
     t1 = max(r[1] for r in st)
     walls.append(t1 - t0); fw.append(t_ce - t0); bw.append(t_opt - t_ce); op.append(t1 - t_opt)
     for q in set(r[3] for r in st):
