@@ -1,5 +1,6 @@
 """Three optimizer steps of the bench workload and nothing else (no timing events, no probes): the process that
-tools/pmc_step.sh wraps in rocprofv3 --pmc. Usage: python tools/one_step.py [slam358m|qwen1p5b]"""
+tools/pmc_step.sh wraps in rocprofv3 --pmc. Usage: python tools/one_step.py [slam358m|slam358m_packed|slam358m_padded|qwen1p5b]
+(slam358m_packed: the recipe's data mode - one flattened [1, 8192] row per micro-batch, GA 4 here; slam358m_padded: right-padded rows)"""
 import os
 import sys
 
@@ -20,6 +21,16 @@ if wl == "slam358m":
     n = float(bench.B * bench.T)
     for i in range(3):
         tr.optimizer_step([bench.synth_batch(0, i, dev)], 1e-3, counts=(n, n))
+elif wl in ("slam358m_packed", "slam358m_padded"):
+    ga = 4 if wl.endswith("packed") else 1
+    model = UnitLM(UnitLMConfig(base_model_name="Qwen/Qwen2.5-0.5B", rope_theta=10000.0, vocab_size=bench.V, max_tokens=bench.B * bench.T), seed=0)
+    tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=bench.B, gradient_accumulation_steps=ga, learning_rate=1e-3,
+                                                          max_grad_norm=0.5, logging_steps=0, optim_state_dtype="bfloat16"))
+    mk = bench.synth_packed_358m if wl.endswith("packed") else bench.synth_padded_358m
+    for i in range(3):
+        micro = [mk(0, 10 * i + j, dev)[0] for j in range(ga)]
+        c = float(sum(int((mb["labels"] != -100).sum()) for mb in micro))
+        tr.optimizer_step(micro, 1e-3, counts=(c, c))
 else:
     model = UnitLM(UnitLMConfig(base_model_name=bench.W4["name"], vocab_size=bench.W4["vocab"], max_tokens=bench.W4["tokens"]), seed=0)
     tr = SLAMTrainer(model=model, args=SLAMTrainingArguments(per_device_train_batch_size=1, learning_rate=5e-4, max_grad_norm=0.5, logging_steps=0))
