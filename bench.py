@@ -155,14 +155,14 @@ def dominant_kernel_roofline(model, iters=50, warm=40):
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
             "ms_per_launch": round(ms, 4),
             # L2-miss-side bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of this
-            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r5_pmc_step.md, row
-            # `gemm_nt_256_kernel<true, false> [256 blocks] fwd`: 233.3 MB read + 239.6 MB written; round 4: 229.1 + 240.2), NOT
+            # same persistent launch inside an optimizer step: a RECORDED measurement (profiles/r6_pmc_step.md, row
+            # `gemm_nt_256_kernel<true, false, false> [256 blocks] fwd`: 231.1 MB read + 239.9 MB written; round 5: 233.3 + 239.6), NOT
             # collected by this run - counters need rocprofv3 around the process (tools/pmc_step.sh). The write side is exactly
             # algorithmic (159.4 MB gate|up + 79.7 MB act); the read side is 7.2x the 32 MB of operands: each of the 8 XCD-private
             # L2s streams the 17.4 MB weight (L2 misses, served by the 256 MB infinity cache after the first XCD: FETCH_SIZE is
             # not HBM reads).
-            "traffic": 472.9e6, "traffic_source": "RECORDED, not measured by this run: profiles/r5_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over "
-                                                  "tools/one_step.py, the same persistent launch, kernels of commit 634cd75 = this kernel unchanged since round 4)",
+            "traffic": 471.0e6, "traffic_source": "RECORDED, not measured by this run: profiles/r6_pmc_step.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over "
+                                                  "tools/one_step.py, the same persistent launch, round-6 library)",
             "algorithmic_bytes": 271.2e6}
 
 

@@ -67,7 +67,7 @@ int gemm_tune_set(GemmTune* t, const char* key, long v) {
       {"gemm_tn224_min_m", &t->tn224_min_m, 0, 1 << 30}, {"gemm_tn224_max_split", &t->tn224_max_split, 1, 16},
       {"gemm_tn_bal_bg_max_split", &t->bal_bg_max_split, 1, 8}, {"gemm_tn224_bg_min_m", &t->tn224_bg_min_m, 0, 1 << 30},
       {"gemm_tn224_bg_max_split", &t->tn224_bg_max_split, 1, 16}, {"gemm_shared", &t->shared, 0, 1}, {"gemm_256_stagger", &t->g256_stagger, 0, 100000}, {"gemm_256_stagger_dswiglu", &t->g256_stagger_dswiglu, 0, 100000},
-      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_256_persist_cus", &t->g256_persist_cus, 0, 4096}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}, {"gemm_256_roles", &t->g256_roles, 0, 1}};
+      {"gemm_256_cohorts", &t->g256_cohorts, 0, 32}, {"gemm_256_persist_cus", &t->g256_persist_cus, 0, 4096}, {"gemm_group_cols_256", &t->group_cols_256, 0, 4096}, {"gemm_mf32", &t->mf32, 0, 1}, {"gemm_256_w4", &t->g256_w4, 0, 1}, {"gemm_256_roles", &t->g256_roles, 0, 1}, {"gemm_256_batch_loads", &t->g256_batch_loads, 0, 1}};
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.f = clamp(v, e.lo, e.hi); return 1; }
   return 0;
@@ -107,6 +107,7 @@ struct GemmArgs {
   int stagger_ticks;  // persistent 256 x 256 blocks with one tile fewer than the longest start this many 10-ns ticks late
   int cohorts;        // > 1: the slots of an XCD in this many contiguous cohorts, cohort c starts c * stagger_ticks late (every block)
   int group_cols;     // > 0: tile rasterisation groups are group_rows x group_cols tiles (0 = group_rows x all columns)
+  int batch_epilogue_loads;  // persistent 256 x 256 SwiGLU backward: gate|up loads of a whole quadrant issued together (dswiglu_tile)
 };
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -381,6 +382,73 @@ SLAM_DEVICE void epilogue8(const GemmArgs& p_, const f32x4_t (&acc)[4][4], int r
       }
     }
   }
+}
+
+// ---- fused SwiGLU backward of a whole 128 x 64 wave tile with its gate|up loads batched (round 6) ---------------------------------
+// epilogue8's SwiGLU-backward path walks one 16-row fragment at a time: 4 loads -> wait -> arithmetic -> 4 stores, eight times per
+// tile and wave. The vector-memory path of a CU is in order, so every one of those load groups queues behind the stores of the
+// fragment before it: eight exposed round trips per tile, each as long as the store queue in front of it (ISA of round 5:
+// `global_load_dwordx4` x4, `s_waitcnt vmcnt(3)`, ..., `global_store_dwordx4` x4, repeat). Here the 16 loads of a 64-row
+// quadrant are issued together, and the second quadrant's loads BEFORE the first quadrant's stores (they go into the registers
+// the first quadrant's accumulators leave behind): two load round trips per tile, neither behind a store. Same arithmetic, same
+// bits (tests: test_gemm_nt_256_persistent_blocks compares with the one-block-per-tile kernel, which keeps epilogue8).
+SLAM_DEVICE void dswiglu_tile(const GemmArgs& p, const f32x4_t (&acc)[2][4][4], int row0, int col0, int wn, int l15, int g) {
+  const int cw = col0 + wn * 64 + g * 8;
+  uint4 gg[2][4][2], uu[2][4][2];  // [quadrant][fm][q]; overwritten in place with the packed d gate / d up
+  auto gptr = [&](int mq, int fm, int q) -> bf16_t* {
+    const int c = cw + 32 * q;
+    return p.gu + (size_t)(row0 + mq * 64 + fm * 16 + l15) * (2 * p.Cn) + (c >> 5) * 64 + (c & 31);
+  };
+  auto load = [&](int mq) {
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bf16_t* gp = gptr(mq, fm, q);
+        gg[mq][fm][q] = *reinterpret_cast<const uint4*>(gp);
+        uu[mq][fm][q] = *reinterpret_cast<const uint4*>(gp + 32);
+      }
+  };
+  auto compute = [&](int mq) {
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float gv[8], uv[8], dg[8], du[8];
+        unpack_bf16x8(gg[mq][fm][q], gv);
+        unpack_bf16x8(uu[mq][fm][q], uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = acc[mq][fm][2 * q + (e >> 2)][e & 3];
+          const float sg = fast_sigmoid(gv[e]);
+          du[e] = d * gv[e] * sg;
+          dg[e] = d * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+        }
+        gg[mq][fm][q] = pack_bf16x8(dg);
+        uu[mq][fm][q] = pack_bf16x8(du);
+      }
+  };
+  auto store = [&](int mq) {
+    if (SLAM_NOSTORE(p.nt_store)) return;
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf16_t* gp = gptr(mq, fm, q);
+        *reinterpret_cast<uint4*>(gp) = gg[mq][fm][q];
+        *reinterpret_cast<uint4*>(gp + 32) = uu[mq][fm][q];
+      }
+  };
+  load(0);
+  __builtin_amdgcn_sched_barrier(0);
+  compute(0);
+  __builtin_amdgcn_sched_barrier(0);
+  load(1);  // ahead of quadrant 0's stores in the CU's in-order memory path
+  __builtin_amdgcn_sched_barrier(0);
+  store(0);
+  __builtin_amdgcn_sched_barrier(0);
+  compute(1);
+  store(1);
 }
 
 // ---- role-split epilogue of the persistent 256 x 256 kernel (round 6, "gemm_256_roles") -------------------------------------------
@@ -1312,6 +1380,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256_kernel(GemmArgs p) {
           if (!loader) quad_drain(p, row0 + mq * 64, col0, wc, l15e, ge, stg);
           raw_barrier();  // the staging region is free again (next quadrant / the DMA of the next tile's second K-tile)
         }
+      } else if (!MF32 && p.gu && p.batch_epilogue_loads) {
+        if constexpr (!MF32) dswiglu_tile(p, acc, row0 + wr * 128, col0, wc, l15e, ge);
       } else {
         store_quadrant(std::true_type{}, 0, l15e, ge);
         store_quadrant(std::true_type{}, 1, l15e, ge);
@@ -2257,6 +2327,7 @@ static int launch_256(GemmArgs a, hipStream_t st) {
   a.stagger_ticks = a.gu ? T().g256_stagger_dswiglu : T().g256_stagger;
   if (a.stagger_ticks > (a.Kc / BK) * 100) a.stagger_ticks = (a.Kc / BK) * 100;  // never more than ~a K loop (1 us per K-tile)
   a.cohorts = T().g256_cohorts;
+  a.batch_epilogue_loads = T().g256_batch_loads;
   const int tiles = a.tiles_r * a.tiles_c;
   // gemm_256_persist_cus > 0: the persistent grid leaves CUs free (a multiple of 8 blocks: one slot count per XCD) - under data
   // parallelism RCCL's kernels need somewhere to start while 256 one-per-CU blocks hold every CU (bench.py extras.dp_variants)

@@ -39,6 +39,9 @@ struct GemmTune {
   // over through LDS) and STORERS (every output store, no vmcnt wait in the K loop): the store drain of a tile runs under the
   // next tile's K loop instead of in front of it (loads and stores share one in-order vmcnt per wave)
   int g256_roles = 0;
+  // round 6: the persistent 256 x 256 SwiGLU-backward epilogue issues the gate|up loads of a 64-row quadrant together and the
+  // second quadrant's before the first one's stores (two load round trips per tile instead of eight, none behind a store)
+  int g256_batch_loads = 1;
 };
 GemmTune* gemm_default_tune();
 GemmTune* gemm_use_tune(GemmTune* t);  // install t (NULL = process default) for this thread; returns the previous one

@@ -216,7 +216,7 @@ class UnitLM(TokenLM):
             self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
             self.flat_grads16 = None       # bf16 gradients of the step's last backward (enable_bf16_grads)
             self._grads_in_bf16 = False    # the last backward left its final values there, not in flat_grads
-        for opt in ("fuse_swiglu", "fuse_dswiglu", "gemm_group_rows", "gemm_glds", "gemm_tn_splits", "gemm_tn_balanced", "gemm_256", "gemm_nt224", "gemm_nt224_min_k", "gemm_256_dswiglu", "gemm_256_persist", "gemm_256_stagger", "gemm_256_stagger_dswiglu", "gemm_256_cohorts", "gemm_256_persist_cus", "gemm_group_cols_256", "gemm_group_rows_256", "gemm_mf32", "gemm_256_w4", "gemm_256_roles", "gemm_tn224", "gemm_tn224_min_m", "gemm_tn224_max_split", "gemm_tn_bal_bg_max_split", "gemm_tn224_bg_min_m", "gemm_tn224_bg_max_split", "bwd_wgrad_stream", "bwd_aux_side", "bwd_wgrad_cus", "attn_jq", "attn_kw", "attn_nch", "attn_prio", "fuse_adamw_t"):  # tuning overrides, e.g. SLAM_FUSE_SWIGLU=0
+        for opt in ("fuse_swiglu", "fuse_dswiglu", "gemm_group_rows", "gemm_glds", "gemm_tn_splits", "gemm_tn_balanced", "gemm_256", "gemm_nt224", "gemm_nt224_min_k", "gemm_256_dswiglu", "gemm_256_persist", "gemm_256_stagger", "gemm_256_stagger_dswiglu", "gemm_256_cohorts", "gemm_256_persist_cus", "gemm_group_cols_256", "gemm_group_rows_256", "gemm_mf32", "gemm_256_w4", "gemm_256_roles", "gemm_256_batch_loads", "gemm_tn224", "gemm_tn224_min_m", "gemm_tn224_max_split", "gemm_tn_bal_bg_max_split", "gemm_tn224_bg_min_m", "gemm_tn224_bg_max_split", "bwd_wgrad_stream", "bwd_aux_side", "bwd_wgrad_cus", "attn_jq", "attn_kw", "attn_nch", "attn_prio", "fuse_adamw_t"):  # tuning overrides, e.g. SLAM_FUSE_SWIGLU=0
             v = os.environ.get("SLAM_" + opt.upper())
             if v is not None:
                 self.engine.set_option(opt, int(v))
