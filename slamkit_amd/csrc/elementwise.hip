@@ -892,6 +892,57 @@ __global__ __launch_bounds__(256) void adamw_tile_kernel(float* __restrict__ p, 
     *reinterpret_cast<uint4*>(dst + 8) = b;
   }
 }
+// The recipe's precision end to end (bf16 parameters, moments AND gradients: round 6) with 16-byte accesses: a thread owns 8
+// consecutive columns (one dwordx4 per array and row instead of two dwordx2), 16 threads per 128-column row segment, 16 rows
+// per pass. Per-element arithmetic = adam_elem<false>: the same bits as the kernel above.
+__global__ __launch_bounds__(256) void adamw_tile_bf16x8_kernel(bf16_t* __restrict__ pb, bf16_t* __restrict__ pt, const bf16_t* __restrict__ g,
+                                                                bf16_t* __restrict__ m, bf16_t* __restrict__ v, int R, int C,
+                                                                size_t batch_stride, const float* __restrict__ clip, AdamHyper h) {
+  constexpr int TC = 128, TPR = TC / 8, RPP = 256 / TPR, NP = 64 / RPP;
+  __shared__ uint16_t T[TC][66];  // transposed bf16 tile: T[col][row], rows padded to 132 B
+  const size_t boff = (size_t)blockIdx.z * batch_stride;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * TC;
+  const int tid = threadIdx.x, rr = tid / TPR, cc = (tid % TPR) * 8;
+  const float cs = clip ? clip[1] : 1.f;
+  uint4 gq[NP], pq[NP], mq[NP], vq[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {  // every load of the tile in flight before the first use
+    const size_t idx = boff + (size_t)(r0 + rr + RPP * i) * C + c0 + cc;
+    gq[i] = *reinterpret_cast<const uint4*>(g + idx);
+    pq[i] = *reinterpret_cast<const uint4*>(pb + idx);
+    mq[i] = *reinterpret_cast<const uint4*>(m + idx);
+    vq[i] = *reinterpret_cast<const uint4*>(v + idx);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = rr + RPP * i;
+    const size_t idx = boff + (size_t)(r0 + row) * C + c0 + cc;
+    float ga[8], pa[8], ma[8], va[8];
+    unpack_bf16x8(gq[i], ga);
+    unpack_bf16x8(pq[i], pa);
+    unpack_bf16x8(mq[i], ma);
+    unpack_bf16x8(vq[i], va);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) adam_elem<false>(pa[j], ma[j], va[j], ga[j] * cs, h);
+    const uint4 po = pack_bf16x8(pa);
+    *reinterpret_cast<uint4*>(pb + idx) = po;
+    *reinterpret_cast<uint4*>(m + idx) = pack_bf16x8(ma);
+    *reinterpret_cast<uint4*>(v + idx) = pack_bf16x8(va);
+    const uint32_t w[4] = {po.x, po.y, po.z, po.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[cc + j][row] = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < TC / 64; ++q) {
+    const int orow = q * 64 + (tid >> 2), seg = (tid & 3) * 16;  // transposed row c0 + orow, its 16 elements r0 + seg ..
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&T[orow][seg]);
+    uint4 a = make_uint4(src[0], src[1], src[2], src[3]), b = make_uint4(src[4], src[5], src[6], src[7]);
+    bf16_t* dst = pt + boff + (size_t)(c0 + orow) * R + r0 + seg;
+    *reinterpret_cast<uint4*>(dst) = a;
+    *reinterpret_cast<uint4*>(dst + 8) = b;
+  }
+}
 // the vectors between the matrices (norm weights, biases): count elements at a constant stride, grid.y = instances
 template <typename MT, bool MASTER, typename GT>
 __global__ __launch_bounds__(256) void adamw_strided_kernel(float* __restrict__ p, bf16_t* __restrict__ pb, GT* __restrict__ g,
@@ -1200,7 +1251,11 @@ int adamw_tiles(int mode, float* p, bf16_t* pb, bf16_t* pt, void* g, int g_bf16,
   static int tile_cols = 128;  // SLAM_ADAMW_TILE_COLS=64: 256-byte row segments (A/B knob)
   static bool read_env = false;
   if (!read_env) { const char* e = getenv("SLAM_ADAMW_TILE_COLS"); if (e && atoi(e) == 64) tile_cols = 64; read_env = true; }
-  if (tile_cols == 128 && (C % 128 == 0)) {
+  static int x8 = -1;  // SLAM_ADAMW_X8=0: the 8-byte-access kernel for the all-bf16 case as well (A/B knob)
+  if (x8 < 0) { const char* e = getenv("SLAM_ADAMW_X8"); x8 = !(e && e[0] == '0'); }
+  if (tile_cols == 128 && (C % 128 == 0) && mode == 2 && g_bf16 && x8) {
+    adamw_tile_bf16x8_kernel<<<dim3(C / 128, R / 64, batch), 256, 0, st>>>(pb, pt, (const bf16_t*)g, (bf16_t*)m, (bf16_t*)v, R, C, batch_stride, clip, h);
+  } else if (tile_cols == 128 && (C % 128 == 0)) {
     const dim3 grid(C / 128, R / 64, batch);
     if (g_bf16) adamw_tiles_launch<128, bf16_t>(mode, grid, p, pb, pt, (bf16_t*)g, m, v, R, C, batch_stride, clip, h, st);
     else adamw_tiles_launch<128, float>(mode, grid, p, pb, pt, (float*)g, m, v, R, C, batch_stride, clip, h, st);
