@@ -944,6 +944,8 @@ def main():
         out["hbm_kernels"] = hbm
         if extras is not None:
             out["extras"] = extras
+            # the attention (and the other shape-dependent) kernels on the recipe's own data modes, next to the dense in-step table
+            roof["in_step"]["recipe_data_modes_us"] = {k: extras[k]["in_step_us"] for k in ("packed_ga16", "padded") if k in extras}
             if "fp32_master_optimizer" in extras:  # like-for-like with rounds 1-3 (fp32 master + fp32 moments), first-class
                 out["value_fp32_master_optimizer"] = extras["fp32_master_optimizer"]["tokens_per_s"]
     # N > 1 (or SLAM_DP_FORCE=1 on one rank): the exchange variants, LAST - the line above is complete without them. A variant
