@@ -779,6 +779,10 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   h->gfinal = 0;
   h->g16 = nullptr;
   if (fin == 2 && !IMG) return h->fail(SLAM_ESTATE, "grad_final_next = 2 needs slam_set_grad_image before the backward");
+  // known from here on: the bucket callbacks below run INSIDE this call, and the engine-side exchange they may start
+  // (slam_allreduce_grads_async / slam_reduce_scatter_grads_async) asks where the gradients live
+  h->gfinal = fin;
+  h->g16 = fin == 2 ? IMG : nullptr;
   const bool partials = fin && !cb && h->norm_partials;  // with a bucket callback the gradients are about to be exchanged: partials of the local ones are of no use
   h->gn_valid = false;
   if (partials) {
@@ -944,8 +948,6 @@ int slam_backward(SlamEngine* h, float grad_scale, int32_t bucket_layers, slam_b
   if (two) CK(edge(ws, st));  // join: everything after slam_backward on `stream` sees complete gradients
   if (cb) cb(user, 0, bucket_end);
   h->have_loss = false;  // a.gu was consumed; a second backward needs a new forward
-  h->gfinal = fin;
-  h->g16 = fin == 2 ? IMG : nullptr;
   h->gn_valid = partials;
   return SLAM_OK;
 }

@@ -127,7 +127,7 @@ class SLAMTrainer:
             # image is ALSO where they live: backward skips the fp32 stores, the reduced values stay in the image (no widening
             # pass), the chunked norm and AdamW read them there
             keep = (self._final_mode == 2 and type(self).optimizer_step is SLAMTrainer.optimizer_step
-                    and self.reducer.stage is getattr(model, "flat_grads16", None))
+                    and self.reducer.stage is not None and self.reducer.stage is getattr(model, "flat_grads16", None))
             armed = self.reducer.arm_image(keep_bf16=keep)
             if keep and armed:
                 model.backward(grad_scale, self.args.ddp_bucket_layers, self.reducer.on_bucket, final=2)
