@@ -437,6 +437,29 @@ b16, ranges2, stage = run(True, True)
 f32_rs, ranges3, _ = run(True, False, rs=True)
 b16_rs, ranges4, _ = run(True, True, rs=True)
 assert ranges3 == ranges4 == ranges0 and torch.equal(f32_rs, plain) and torch.equal(b16_rs, b16)
+# gradients KEPT in the bf16 image (grad_final_next = 2): the exchange reduces the image in place and must not widen it back
+def run_final2(rs):
+    m.zero_grad()
+    m(input_ids=ids, labels=ids, return_logits=False)
+    stage = torch.full((eng.n_params,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    m.flat_grads.fill_(float("nan"))
+    eng.set_grad_image(stage)
+    def cb(off, cnt, ready):
+        (eng.reduce_scatter_grads_async if rs else eng.allreduce_grads_async)(off, cnt, True, ready)
+    eng.set_option("grad_overwrite_next", 1)
+    eng.backward(1.0, 1, cb, final=2)
+    eng.comm_finish()
+    norm = torch.zeros(2, device="cuda")
+    eng.grad_norm(0.0, norm)   # a backward that reported buckets: chunk sums over the image, not the partials
+    torch.cuda.synchronize()
+    return stage, m.flat_grads.clone(), float(norm[0])
+for rs in (False, True):
+    stage2, f32buf, nrm = run_final2(rs)
+    assert torch.equal(stage2.float(), b16), ("final2", rs)
+    emb = eng.tensors["embed"].numel
+    assert bool(torch.isnan(f32buf[emb:]).all()), "the fp32 buffer was written behind the embedding (widening pass or fp32 final stores)"
+    ref = float(b16.double().norm())
+    assert abs(nrm - ref) <= 2e-6 * ref, (nrm, ref)
 p0 = m.flat_params.clone()
 for off, cnt in sorted(ranges0):
     eng.allgather_params_async(off, cnt)
