@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
 # of the headline step takes the plan it takes there (M = 8 x 1024 tokens)
 SLAM2 = O.OracleConfig(vocab=502, hidden=896, n_layers=2, n_heads=14, n_kv_heads=2, head_dim=64, intermediate=4864)
 BIGV = O.OracleConfig(vocab=5003, hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, intermediate=512)
+# two layers of the configs[3]-shaped body (Qwen2.5-1.5B dims, head_dim 128): the 256 x 224 weight-gradient kernel in its other tile
+# counts and orientations (Wgu 17920 x 1536 transposed-store, Wd 1536 x 8960 direct), 128 x 128 plans of other sizes
+QW2 = O.OracleConfig(vocab=700, hidden=1536, n_layers=2, n_heads=12, n_kv_heads=2, head_dim=128, intermediate=8960, rope_theta=1e6)
 
 
 def _batch(cfg, B, T, seed):
@@ -41,7 +44,8 @@ def _run(m, batches, final):
     return m.flat_grads.clone(), (m.flat_grads16.clone() if final == 2 else None), norm.cpu()
 
 
-@pytest.mark.parametrize("cfg,B,T", [(O.TINY, 2, 96), (SLAM2, 8, 1024), (SLAM2, 3, 704), (BIGV, 2, 320)], ids=["tiny", "slam2", "slam2_ragged", "bigvocab"])
+@pytest.mark.parametrize("cfg,B,T", [(O.TINY, 2, 96), (SLAM2, 8, 1024), (SLAM2, 3, 704), (BIGV, 2, 320), (QW2, 2, 2048)],
+                         ids=["tiny", "slam2", "slam2_ragged", "bigvocab", "qwen1p5b_2layers"])
 @pytest.mark.parametrize("ga", [1, 2])
 def test_final_bf16_gradients_are_the_rounded_fp32_ones(cfg, B, T, ga):
     sd = O.init_weights(cfg, seed=5, bias_std=0.02, norm_jitter=0.05)
